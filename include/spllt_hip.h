@@ -1,0 +1,122 @@
+/*
+ * spllt_hip.h -- additions of libspllt_hip.so next to the drop-in ABI of
+ * spllt_iface.h.  Two groups:
+ *
+ *  (1) the per-kernel operator API.  The reference already exposes its factor
+ *      kernels as bind(C) routines for the StarPU/PaRSEC task bodies
+ *      (src/spllt_kernels_mod.F90:1193,1233,1295,2055,2241 and the CUDA launcher
+ *      src/StarPU/expand_buffer_kernels.cu:48-62).  These are their
+ *      stream-taking twins: same argument meaning, device pointers, plain
+ *      index arrays instead of Fortran derived-type handles, asynchronous on
+ *      the given HIP stream (passed as void* so that the header needs no HIP).
+ *
+ *  (2) engine control / introspection used by benchmarks and tests
+ *      (exact 64-bit statistics, device-resident factorization, L download,
+ *      export of the symbolic structure and of the stream-DAG program).
+ */
+#ifndef SPLLT_HIP_H
+#define SPLLT_HIP_H
+#include <stdint.h>
+
+#include "spllt_iface.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) kernel operators: all pointers are DEVICE pointers ---------------- */
+
+/* twin of spllt_factor_diag_block_c(m, n, bc) (kernels_mod:1193): Cholesky of
+ * the n x n head of a row-major m x n diagonal tile and the triangular solve
+ * of its m-n trailing rows.  *dev_flag (int, device) receives min(column+1) of
+ * a non-positive pivot, untouched otherwise (initialise it to INT_MAX). */
+int spllt_factor_diag_block_hip(void *stream, int m, int n, double *bc, int *dev_flag);
+
+/* twin of spllt_solve_block_c(m, n, bc_kk, bc_ik) (kernels_mod:1233):
+ * bc_ik <- bc_ik * L_kk^-T, bc_ik is m x n row-major, bc_kk the factored n x n tile. */
+int spllt_solve_block_hip(void *stream, int m, int n, const double *bc_kk, double *bc_ik);
+
+/* twin of spllt_update_block_c(m, n, dest, isDiag, n1, src1, src2)
+ * (kernels_mod:1295): dest -= src2 * src1^T; src1 is n x n1, src2 is m x n1. */
+int spllt_update_block_hip(void *stream, int m, int n, double *dest, int is_diag, int n1,
+                           const double *src1, const double *src2);
+
+/* twin of spllt_update_between_c (kernels_mod:2241) with the index lists of
+ * spllt_update_between_compute_map_c (:1725) passed explicitly and the
+ * spllt_expand_buffer_c step (:2055) fused into the GEMM epilogue:
+ *   dest[row_list[i]*blkn + col_list[j]] -= sum_k rsrc[i][k] * csrc[j][k],
+ * i < rls, j < (i < ndiag ? i+1 : cls); csrc is cls x n1, rsrc is rls x n1,
+ * row_list/col_list are 0-based device arrays. */
+int spllt_update_between_hip(void *stream, double *dest, int blkn, int n1, const double *csrc,
+                             int cls, const double *rsrc, int rls, const int *row_list,
+                             const int *col_list, int ndiag);
+
+/* twin of spllt_expand_buffer_c (kernels_mod:2055) / spllt_cu_expand_buffer
+ * (StarPU/expand_buffer_kernels.cu:48): a[row_list[j]*blkn + col_list[i]] +=
+ * buffer[j*cls + i], i < (j < ndiag ? j+1 : cls). */
+int spllt_expand_buffer_hip(void *stream, double *a, int blkn, const int *row_list, int rls,
+                            const int *col_list, int cls, int ndiag, const double *buffer);
+
+/* twin of spllt_scatter_block (kernels_mod:1122): dest -= src with row/column
+ * positions located in the destination index lists (all sorted, device). */
+int spllt_scatter_block_hip(void *stream, int s_m, int s_n, const int *rsrc_index,
+                            const int *csrc_index, const double *src, int lds,
+                            const int *rdest_index, int d_m, const int *cdest_index, int d_n,
+                            double *dest, int ldd);
+
+/* twin of spllt_init_node_c / spllt_init_blk_c (kernels_mod:2367, :2425) for
+ * the whole arena: L[dst[i]] = val[src[i]], i < n (L zeroed by the caller). */
+int spllt_init_lfact_hip(void *stream, double *L, const double *val, const int64_t *dst,
+                         const int64_t *src, int64_t n);
+
+/* ---- (2) engine control / introspection ----------------------------------- */
+
+typedef struct {
+  int64_t n, nnz_a, nnodes, nbcol, nblk, arena, nnz_l, flops, rlist_len;
+  int nb, maxmn, maxdepth, nlevels;
+  char ordering[16];
+} spllt_hip_sym_info_t;
+
+/* analyse with a caller-supplied pivot order (order_in[i] = 1-based position
+ * of variable i; NULL = built-in nested dissection).  Otherwise identical to
+ * spllt_analyse. */
+void spllt_hip_analyse_ordered(void **akeep, void **fkeep, spllt_options_t *options, int n,
+                               const int *ptr, const int *row, spllt_inform_t *info, int *order,
+                               const int *order_in);
+
+int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
+/* copy a named 0-based array of the symbolic structure; returns its length in
+ * elements (call with buf = NULL to query).  int32 arrays: "order", "sptr",
+ * "sparent", "rlist", "small", "level", "bcol_node", "bcol_width", "bcol_r0",
+ * "bcol_nrow"; int64 arrays: "rptr", "bcol_off", "map_dst", "map_src",
+ * "lmap_ptr", "weight". */
+int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_t capacity);
+
+/* engine knobs (before the first spllt_factor on this fkeep) */
+int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int use_graph);
+
+/* spllt_factor with val already resident in HBM (device pointer) */
+void spllt_hip_factor_dev(void *akeep, void *fkeep, spllt_options_t *options, int nnz,
+                          const double *val_dev, spllt_inform_t *info);
+/* wait for ONE factorization and return its flag (spllt_wait() has no way to) */
+int spllt_hip_wait(void *fkeep);
+/* copy the whole L arena (block columns concatenated in order) to host memory */
+int spllt_hip_get_factor(void *fkeep, double *out, int64_t count);
+/* device pointer of the L arena (valid until spllt_deallocate_fkeep) */
+double *spllt_hip_device_factor(void *fkeep);
+/* timings of the last factorization, milliseconds */
+int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, double *h2d_ms,
+                           int *launches);
+/* program export for tests: "launches" (int64 x 6 per launch: kind, level,
+ * first, count, tile, flops), "potrf" (PotrfUnit bytes), "units" (UpdUnit
+ * bytes), "tiles" (UpdTile bytes), "relpos" (int32).  Returns byte length. */
+int64_t spllt_hip_program_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
+/* per-launch device time (ms) of one profiled factorization; returns #launches */
+int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int capacity);
+const char *spllt_hip_last_error(const void *fkeep);
+const char *spllt_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,536 @@
+// extern "C" boundary of libspllt_hip.so: the SpLLT C-ABI (include/spllt_iface.h)
+// plus the extensions of include/spllt_hip.h.  Mirrors the behaviour of
+// reference interfaces/C/spllt_data_ciface.F90: never aborts, messages on
+// stderr, status in info->flag.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "hostsolve.hpp"
+#include "kernels.hpp"
+#include "spllt_hip.h"
+#include "symbolic.hpp"
+
+using namespace spx;
+
+namespace {
+
+struct Akeep {
+  std::shared_ptr<Symbolic> S;
+  SymOptions so;
+};
+
+struct Fkeep {
+  std::shared_ptr<Symbolic> S;
+  std::unique_ptr<Engine> eng;
+  EngineOptions eo;
+  std::vector<double> hostL;
+  bool hostL_valid = false;
+  int last_flag = 0;
+  std::string last_error;
+  // solve memory handed over by spllt_set_mem_solve (borrowed, unused by the host solve)
+  double* y = nullptr;
+  double* workspace = nullptr;
+  long worksize = 0;
+};
+
+std::mutex g_mu;
+std::vector<Fkeep*> g_pending;  // factorizations submitted and not yet waited for
+
+void clear_info(spllt_inform_t* info) {
+  if (!info) return;
+  std::memset(info, 0, sizeof(*info));
+}
+
+void fill_info(const Symbolic& S, spllt_inform_t* info) {
+  if (!info) return;
+  info->maxdepth = S.maxdepth;
+  info->num_factor = (int)S.nnzL;  // truncated like the reference (ciface:77-78)
+  info->num_flops = (int)S.flops;
+  info->num_nodes = S.nnodes;
+  info->stat = 0;
+}
+
+int do_wait(Fkeep* f) {
+  if (!f->eng) return f->last_flag;
+  if (f->eng->pending()) {
+    int rc = f->eng->wait();
+    f->last_flag = rc;
+    f->hostL_valid = false;
+    if (rc == SPLLT_ERROR_NOT_POSDEF) {
+      char buf[160];
+      std::snprintf(buf, sizeof buf, "matrix is not positive definite (pivot column %d in elimination order)",
+                    f->eng->not_posdef_column() + 1);
+      f->last_error = buf;
+      std::fprintf(stderr, "spllt-hip: %s\n", buf);
+    } else if (rc) {
+      f->last_error = f->eng->error();
+    }
+  }
+  return f->last_flag;
+}
+
+int ensure_hostL(Fkeep* f) {
+  do_wait(f);
+  if (f->last_flag) return f->last_flag;
+  if (!f->eng) return SPLLT_ERROR_PARAMETER;
+  if (!f->hostL_valid) {
+    f->hostL.resize((size_t)f->S->arena);
+    int rc = f->eng->download(f->hostL.data(), f->S->arena);
+    if (rc) return rc;
+    f->hostL_valid = true;
+  }
+  return 0;
+}
+
+void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, const int* ptr,
+                  const int* row, spllt_inform_t* info, int* order, const int* order_in) {
+  clear_info(info);
+  if (!akeep || !fkeep || !options || !ptr || !row || n < 0) {
+    std::fprintf(stderr, "spllt-hip: spllt_analyse: invalid argument\n");
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  Akeep* a = static_cast<Akeep*>(*akeep);
+  Fkeep* f = static_cast<Fkeep*>(*fkeep);
+  if (!a) { a = new (std::nothrow) Akeep(); *akeep = a; }
+  if (!f) { f = new (std::nothrow) Fkeep(); *fkeep = f; }
+  if (!a || !f) { if (info) info->flag = SPLLT_ERROR_ALLOCATION; return; }
+  a->so.nb = options->nb;
+  a->so.nemin = options->nemin;
+  a->so.prune_tree = options->prune_tree != 0;
+  a->so.ncpu = options->ncpu;
+  // 1-based int CSC -> 0-based
+  std::vector<int64_t> p0((size_t)n + 1);
+  for (int j = 0; j <= n; ++j) p0[j] = (int64_t)ptr[j] - 1;
+  const int64_t nz = n > 0 ? p0[n] : 0;
+  std::vector<int> r0((size_t)std::max<int64_t>(1, nz));
+  for (int64_t e = 0; e < nz; ++e) r0[e] = row[e] - 1;
+  std::vector<int> uo;
+  if (order_in) {
+    uo.resize(n);
+    for (int i = 0; i < n; ++i) uo[i] = order_in[i] - 1;
+  }
+  auto S = std::make_shared<Symbolic>();
+  int rc;
+  try {
+    rc = analyse(n, p0.data(), r0.data(), order_in ? uo.data() : nullptr, a->so, *S);
+  } catch (const std::bad_alloc&) {
+    rc = SPLLT_ERROR_ALLOCATION;
+  }
+  if (rc) {
+    std::fprintf(stderr, "spllt-hip: spllt_analyse failed with flag %d\n", rc);
+    if (info) info->flag = rc;
+    return;
+  }
+  a->S = S;
+  f->S = S;
+  f->eng.reset();
+  f->hostL_valid = false;
+  f->last_flag = 0;
+  if (order)
+    for (int i = 0; i < n; ++i) order[i] = S->order[i] + 1;
+  fill_info(*S, info);
+}
+
+void factor_impl(void* akeep, void* fkeep, int nnz, const double* val, bool dev, spllt_inform_t* info) {
+  clear_info(info);
+  Akeep* a = static_cast<Akeep*>(akeep);
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!a || !f || !f->S || !val) {
+    std::fprintf(stderr, "spllt-hip: spllt_factor: akeep/fkeep/val provided by the user is empty\n");
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  if ((int64_t)nnz != f->S->nnzA) {
+    std::fprintf(stderr, "spllt-hip: spllt_factor: nnz = %d does not match the analysed pattern (%lld)\n", nnz,
+                 (long long)f->S->nnzA);
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  if (f->eng && f->eng->pending()) do_wait(f);
+  if (!f->eng) {
+    f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+    if (!f->eng) { if (info) info->flag = SPLLT_ERROR_ALLOCATION; return; }
+  }
+  if (f->eng->status()) {
+    f->last_flag = f->eng->status();
+    f->last_error = f->eng->error();
+    if (info) info->flag = f->last_flag;
+    return;
+  }
+  int rc = dev ? f->eng->factor_async_dev(val, nnz) : f->eng->factor_async(val, nnz);
+  f->last_flag = rc;
+  f->hostL_valid = false;
+  if (rc == 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (std::find(g_pending.begin(), g_pending.end(), f) == g_pending.end()) g_pending.push_back(f);
+  } else {
+    f->last_error = f->eng->error();
+  }
+  fill_info(*f->S, info);
+  if (info) info->flag = rc;
+}
+
+template <class Tp>
+static int64_t copy_out(const std::vector<Tp>& v, void* buf, int64_t cap) {
+  if (buf) {
+    int64_t k = std::min<int64_t>(cap, (int64_t)v.size());
+    if (k > 0) std::memcpy(buf, v.data(), sizeof(Tp) * (size_t)k);
+  }
+  return (int64_t)v.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+void spllt_analyse(void** akeep, void** fkeep, spllt_options_t* options, int n, int* ptr, int* row,
+                   spllt_inform_t* info, int* order) {
+  analyse_impl(akeep, fkeep, options, n, ptr, row, info, order, nullptr);
+}
+
+void spllt_hip_analyse_ordered(void** akeep, void** fkeep, spllt_options_t* options, int n,
+                               const int* ptr, const int* row, spllt_inform_t* info, int* order,
+                               const int* order_in) {
+  analyse_impl(akeep, fkeep, options, n, ptr, row, info, order, order_in);
+}
+
+void spllt_factor(void* akeep, void* fkeep, spllt_options_t* options, int nnz, double* val,
+                  spllt_inform_t* info) {
+  (void)options;
+  factor_impl(akeep, fkeep, nnz, val, false, info);
+}
+
+void spllt_hip_factor_dev(void* akeep, void* fkeep, spllt_options_t* options, int nnz,
+                          const double* val_dev, spllt_inform_t* info) {
+  (void)options;
+  factor_impl(akeep, fkeep, nnz, val_dev, true, info);
+}
+
+void spllt_wait(void) {
+  std::vector<Fkeep*> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    todo.swap(g_pending);
+  }
+  for (Fkeep* f : todo) do_wait(f);
+}
+
+int spllt_hip_wait(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f) return SPLLT_ERROR_PARAMETER;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.erase(std::remove(g_pending.begin(), g_pending.end(), f), g_pending.end());
+  }
+  return do_wait(f);
+}
+
+void spllt_solve_workspace_size(void* fkeep, int nworker, int nrhs, long* size) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!size) return;
+  *size = 0;
+  if (!f || !f->S) return;
+  if (nworker < 1) nworker = 1;
+  // reference formula, src/spllt_data_mod.F90:655
+  *size = (long)f->S->n * nrhs + ((long)f->S->maxmn + f->S->n) * nrhs * nworker;
+}
+
+void spllt_prepare_solve(void* akeep, void* fkeep, int nb, int nrhs, long* worksize,
+                         spllt_inform_t* info) {
+  (void)akeep; (void)nb;
+  clear_info(info);
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S) {
+    std::fprintf(stderr, "spllt-hip: Error, fkeep provided by the user is empty\n");
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  spllt_solve_workspace_size(fkeep, 1, nrhs, worksize);
+  fill_info(*f->S, info);
+}
+
+void spllt_set_mem_solve(void* akeep, void* fkeep, int nb, int nrhs, long worksize, double* y,
+                         double* workspace, spllt_inform_t* info) {
+  (void)akeep; (void)nb; (void)nrhs;
+  clear_info(info);
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S) {
+    std::fprintf(stderr, "spllt-hip: Error, fkeep provided by the user is empty\n");
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  if (!y) std::fprintf(stderr, "spllt-hip: Error, y provided by the user is empty\n");
+  if (!workspace) std::fprintf(stderr, "spllt-hip: Error, workspace provided by the user is empty\n");
+  f->y = y;
+  f->workspace = workspace;
+  f->worksize = worksize;
+  fill_info(*f->S, info);
+}
+
+void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, double* x,
+                 spllt_inform_t* info, int job) {
+  (void)options; (void)order;  // `order` is ignored by the reference too (ciface:404-419)
+  clear_info(info);
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !x) {
+    std::fprintf(stderr, "spllt-hip: Error, fkeep/x provided by the user is empty\n");
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  if (job < 0 || job > 2) {
+    // reference src/spllt_solve_mod.F90:216-220
+    std::fprintf(stderr, "Unknown requested job = %2d returned code : %4d\n", job, SPLLT_ERROR_PARAMETER);
+    if (info) info->flag = SPLLT_ERROR_PARAMETER;
+    return;
+  }
+  int rc = ensure_hostL(f);
+  if (rc) { if (info) info->flag = rc; return; }
+  host_solve(*f->S, f->hostL.data(), nrhs, x, job);
+  fill_info(*f->S, info);
+}
+
+void spllt_solve_worker(void* fkeep, spllt_options_t* options, int* order, int nrhs, double* x,
+                        spllt_inform_t* info, int job, double* workspace, long worksize, void* tm) {
+  (void)workspace; (void)worksize; (void)tm;
+  spllt_solve(fkeep, options, order, nrhs, x, info, job);
+}
+
+// reference src/utils_mod.F90:432-478 (check_backward_error_multi): scaled
+// backward error ||b - A x||_2 / (||b||_2 + max|a_ij| ||x||_2), pass <= 1e-14.
+void spllt_chkerr(int n, int* ptr, int* row, double* val, int nrhs, double* x, double* rhs) {
+  if (!ptr || !row || !val || !x || !rhs) {
+    std::fprintf(stderr, "spllt-hip: Error, an array provided by the user is empty\n");
+    return;
+  }
+  double amax = 0;
+  for (int e = 0; e < ptr[n] - 1; ++e) amax = std::max(amax, std::fabs(val[e]));
+  int ok = 0;
+  std::vector<double> res(n);
+  for (int r = 0; r < nrhs; ++r) {
+    const double* xr = x + (int64_t)r * n;
+    const double* br = rhs + (int64_t)r * n;
+    for (int i = 0; i < n; ++i) res[i] = br[i];
+    for (int j = 0; j < n; ++j)
+      for (int e = ptr[j] - 1; e < ptr[j + 1] - 1; ++e) {
+        int i = row[e] - 1;
+        res[i] -= val[e] * xr[j];
+        if (i != j) res[j] -= val[e] * xr[i];
+      }
+    double nr = 0, nb = 0, nx = 0;
+    for (int i = 0; i < n; ++i) { nr += res[i] * res[i]; nb += br[i] * br[i]; nx += xr[i] * xr[i]; }
+    double err = std::sqrt(nr) / (std::sqrt(nb) + amax * std::sqrt(nx));
+    if (err != err) {
+      std::printf("Backward error of rhs %3d is equal to a NAN\n", r + 1);
+    } else if (err > 1e-14) {
+      std::fprintf(stderr, "Wrong Bwd error for %4d/%4d : %10.2e\n", r + 1, nrhs, err);
+    } else {
+      std::fprintf(stderr, "Bwd error for %4d/%4d : %10.2e\n", r + 1, nrhs, err);
+      ok++;
+    }
+  }
+  std::fprintf(stderr, "Backward error... ok for %3d/%3d\n", ok, nrhs);
+}
+
+void spllt_deallocate_fkeep(void** fkeep, int* stat) {
+  if (stat) *stat = 0;
+  if (!fkeep || !*fkeep) return;
+  Fkeep* f = static_cast<Fkeep*>(*fkeep);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.erase(std::remove(g_pending.begin(), g_pending.end(), f), g_pending.end());
+  }
+  delete f;
+  *fkeep = nullptr;
+}
+
+void spllt_deallocate_akeep(void** akeep, int* stat) {
+  if (stat) *stat = 0;
+  if (!akeep || !*akeep) return;
+  delete static_cast<Akeep*>(*akeep);
+  *akeep = nullptr;
+}
+
+// The reference's task manager drives the OpenMP solve tasks; the stream-DAG
+// engine needs none.  A token object keeps init/deallocate pairs well-formed.
+void spllt_task_manager_init(void** task_manager) {
+  if (task_manager) *task_manager = new int(0);
+}
+void spllt_task_manager_deallocate(void** task_manager, int* stat) {
+  if (stat) *stat = 0;
+  if (!task_manager || !*task_manager) return;
+  delete static_cast<int*>(*task_manager);
+  *task_manager = nullptr;
+}
+
+void spllt_all(void** akeep, void** fkeep, spllt_options_t* options, int n, int nnz, int nrhs,
+               int nb, int* ptr, int* row, double* val, double* x, double* rhs,
+               spllt_inform_t* info) {
+  if (options) options->nb = nb;
+  std::vector<int> order((size_t)std::max(1, n));
+  spllt_analyse(akeep, fkeep, options, n, ptr, row, info, order.data());
+  if (info && info->flag < 0) return;
+  spllt_factor(*akeep, *fkeep, options, nnz, val, info);
+  if (info && info->flag < 0) return;
+  int rc = spllt_hip_wait(*fkeep);
+  if (rc) { if (info) info->flag = rc; return; }
+  long ws = 0;
+  spllt_prepare_solve(*akeep, *fkeep, nb, nrhs, &ws, info);
+  if (x != rhs) std::memcpy(x, rhs, sizeof(double) * (size_t)n * nrhs);
+  spllt_solve(*fkeep, options, order.data(), nrhs, x, info, 0);
+  if (info && info->flag < 0) return;
+  spllt_chkerr(n, ptr, row, val, nrhs, x, rhs);
+}
+
+// ---------------------------------------------------------------------------
+// extensions
+// ---------------------------------------------------------------------------
+int spllt_hip_sym_info(const void* akeep, spllt_hip_sym_info_t* out) {
+  const Akeep* a = static_cast<const Akeep*>(akeep);
+  if (!a || !a->S || !out) return SPLLT_ERROR_PARAMETER;
+  const Symbolic& S = *a->S;
+  std::memset(out, 0, sizeof(*out));
+  out->n = S.n; out->nnz_a = S.nnzA; out->nnodes = S.nnodes; out->nbcol = S.nbcol();
+  out->nblk = S.nblk; out->arena = S.arena; out->nnz_l = S.nnzL; out->flops = S.flops;
+  out->rlist_len = (int64_t)S.rlist.size();
+  out->nb = S.nb; out->maxmn = S.maxmn; out->maxdepth = S.maxdepth;
+  int nl = 0;
+  for (int s = 0; s < S.nnodes; ++s) nl = std::max(nl, S.level[s] + 1);
+  out->nlevels = nl;
+  std::snprintf(out->ordering, sizeof out->ordering, "%s", S.ordering.c_str());
+  return 0;
+}
+
+int64_t spllt_hip_sym_get(const void* akeep, const char* name, void* buf, int64_t cap) {
+  const Akeep* a = static_cast<const Akeep*>(akeep);
+  if (!a || !a->S || !name) return -1;
+  const Symbolic& S = *a->S;
+  std::string k(name);
+  if (k == "order") return copy_out(S.order, buf, cap);
+  if (k == "sptr") return copy_out(S.sptr, buf, cap);
+  if (k == "sparent") return copy_out(S.sparent, buf, cap);
+  if (k == "rlist") return copy_out(S.rlist, buf, cap);
+  if (k == "small") return copy_out(S.small, buf, cap);
+  if (k == "level") return copy_out(S.level, buf, cap);
+  if (k == "rptr") return copy_out(S.rptr, buf, cap);
+  if (k == "map_dst") return copy_out(S.map_dst, buf, cap);
+  if (k == "map_src") return copy_out(S.map_src, buf, cap);
+  if (k == "lmap_ptr") return copy_out(S.lmap_ptr, buf, cap);
+  if (k == "weight") return copy_out(S.weight, buf, cap);
+  if (k == "node_bcol0") return copy_out(S.node_bcol0, buf, cap);
+  if (k.rfind("bcol_", 0) == 0) {
+    const int nb = S.nbcol();
+    if (k == "bcol_off") {
+      std::vector<int64_t> v(nb);
+      for (int b = 0; b < nb; ++b) v[b] = S.bcols[b].off;
+      return copy_out(v, buf, cap);
+    }
+    std::vector<int> v(nb);
+    for (int b = 0; b < nb; ++b) {
+      const BlockCol& B = S.bcols[b];
+      v[b] = k == "bcol_node" ? B.node : k == "bcol_width" ? B.width : k == "bcol_r0" ? B.r0 : k == "bcol_nrow" ? B.nrow : -1;
+    }
+    return copy_out(v, buf, cap);
+  }
+  return -1;
+}
+
+int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f) return SPLLT_ERROR_PARAMETER;
+  if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
+  if (panel_width > 0) f->eo.pw = std::min(panel_width, kPanelMax);
+  if (tile > 0) f->eo.tile = tile;
+  f->eo.use_graph = use_graph != 0;
+  return 0;
+}
+
+int spllt_hip_get_factor(void* fkeep, double* out, int64_t count) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !out) return SPLLT_ERROR_PARAMETER;
+  int rc = ensure_hostL(f);
+  if (rc) return rc;
+  std::memcpy(out, f->hostL.data(), sizeof(double) * (size_t)std::min<int64_t>(count, f->S->arena));
+  return 0;
+}
+
+double* spllt_hip_device_factor(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  return (f && f->eng) ? f->eng->device_L() : nullptr;
+}
+
+int spllt_hip_factor_times(void* fkeep, double* submit_ms, double* device_ms, double* h2d_ms, int* launches) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->eng) return SPLLT_ERROR_PARAMETER;
+  const FactorStats& st = f->eng->stats();
+  if (submit_ms) *submit_ms = st.submit_ms;
+  if (device_ms) *device_ms = st.device_ms;
+  if (h2d_ms) *h2d_ms = st.h2d_ms;
+  if (launches) *launches = st.launches;
+  return 0;
+}
+
+int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t cap) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !name) return -1;
+  // The program can be inspected without a GPU: build it on demand.
+  Program local;
+  const Program* P;
+  if (f->eng && !f->eng->status()) {
+    P = &f->eng->program();
+  } else {
+    ScheduleOptions so;
+    so.pw = f->eo.pw;
+    so.tile = f->eo.tile;
+    build_program(*f->S, so, local);
+    P = &local;
+  }
+  std::string k(name);
+  auto raw = [&](const void* p, size_t bytes) -> int64_t {
+    if (buf && bytes) std::memcpy(buf, p, std::min<size_t>(bytes, (size_t)cap));
+    return (int64_t)bytes;
+  };
+  if (k == "launches") {
+    std::vector<int64_t> v;
+    for (const Launch& l : P->launches) {
+      v.push_back(l.kind); v.push_back(l.level); v.push_back(l.first);
+      v.push_back(l.count); v.push_back(l.tile); v.push_back((int64_t)l.flops);
+    }
+    return raw(v.data(), v.size() * sizeof(int64_t));
+  }
+  if (k == "potrf") return raw(P->potrf_units.data(), P->potrf_units.size() * sizeof(PotrfUnit));
+  if (k == "units") return raw(P->units.data(), P->units.size() * sizeof(UpdUnit));
+  if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
+  if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
+  if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
+  return -1;
+}
+
+int spllt_hip_profile(void* fkeep, const double* val, int nnz, float* ms, int capacity) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !val) return SPLLT_ERROR_PARAMETER;
+  if (!f->eng) f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+  if (!f->eng || f->eng->status()) return SPLLT_ERROR_HIP;
+  std::vector<float> v;
+  int rc = f->eng->profile_launches(val, nnz, v);
+  if (rc) return rc;
+  for (int i = 0; i < (int)v.size() && i < capacity; ++i) ms[i] = v[i];
+  f->hostL_valid = false;
+  return (int)v.size();
+}
+
+const char* spllt_hip_last_error(const void* fkeep) {
+  const Fkeep* f = static_cast<const Fkeep*>(fkeep);
+  return f ? f->last_error.c_str() : "";
+}
+
+const char* spllt_hip_version(void) { return "spllt-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// Engine implementation (HIP runtime API; compiled by hipcc as host code).
+#include "engine.hpp"
+
+#include <chrono>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace spx {
+
+namespace {
+constexpr int kErrAlloc = -1, kErrHip = -30, kErrNotPosDef = -20;
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+#define HIPCHK(call, what)                                   \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return fail(kErrHip, what, e__);  \
+  } while (0)
+
+int Engine::fail(int code, const char* what, hipError_t e) {
+  status_ = code;
+  err_ = std::string(what) + ": " + hipGetErrorString(e);
+  std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
+  return code;
+}
+
+template <class Tp>
+static hipError_t dev_upload(Tp** dptr, const std::vector<Tp>& v) {
+  size_t bytes = sizeof(Tp) * (v.empty() ? 1 : v.size());
+  hipError_t e = hipMalloc((void**)dptr, bytes);
+  if (e != hipSuccess) return e;
+  if (!v.empty()) e = hipMemcpy(*dptr, v.data(), sizeof(Tp) * v.size(), hipMemcpyHostToDevice);
+  return e;
+}
+
+Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
+    : S_(std::move(S)), opt_(opt) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    // The product has no CPU path: fail loudly.
+    status_ = kErrHip;
+    err_ = "no HIP device available (the factorize path runs only on gfx950)";
+    std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
+    return;
+  }
+  hipGetDevice(&device_);
+  ScheduleOptions so;
+  so.pw = opt_.pw;
+  so.tile = opt_.tile;
+  build_program(*S_, so, prog_);
+  upload();
+}
+
+int Engine::upload() {
+  const Symbolic& S = *S_;
+  HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
+  HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
+  HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
+  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "hipMalloc(L arena)");
+  HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
+  HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)std::max<int64_t>(1, prog_.dinv_size)), "hipMalloc(dinv)");
+  HIPCHK(dev_upload(&d_map_dst_, S.map_dst), "upload map_dst");
+  HIPCHK(dev_upload(&d_map_src_, S.map_src), "upload map_src");
+  std::vector<int64_t> off(S.nbcol());
+  std::vector<int> w(S.nbcol());
+  for (int b = 0; b < S.nbcol(); ++b) { off[b] = S.bcols[b].off; w[b] = S.bcols[b].width; }
+  HIPCHK(dev_upload(&d_bc_off_, off), "upload bc_off");
+  HIPCHK(dev_upload(&d_bc_w_, w), "upload bc_w");
+  HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
+  HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
+  HIPCHK(dev_upload(&d_potrf_, prog_.potrf_units), "upload potrf units");
+  HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
+  HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
+  HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
+  HIPCHK(hipHostMalloc((void**)&h_flag_, sizeof(int), hipHostMallocDefault), "hipHostMalloc(flag)");
+  return 0;
+}
+
+Engine::~Engine() {
+  if (stream_) hipStreamSynchronize(stream_);
+  if (graph_exec_) hipGraphExecDestroy(graph_exec_);
+  if (graph_) hipGraphDestroy(graph_);
+  hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_);
+  hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
+  if (h_flag_) hipHostFree(h_flag_);
+  if (ev0_) hipEventDestroy(ev0_);
+  if (ev1_) hipEventDestroy(ev1_);
+  if (ev_h2d_) hipEventDestroy(ev_h2d_);
+  if (stream_) hipStreamDestroy(stream_);
+}
+
+int Engine::enqueue_launch(const Launch& l) {
+  if (l.kind == L_POTRF)
+    launch_potrf(stream_, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
+  else
+    launch_update(stream_, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_,
+                  d_L_, d_relpos_, d_rlist_, d_dinv_);
+  return 0;
+}
+
+int Engine::enqueue_program() {
+  const Symbolic& S = *S_;
+  HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
+  const int big = INT_MAX;
+  *h_flag_ = big;
+  HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
+  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, S.nnzA);
+  for (const Launch& l : prog_.launches) enqueue_launch(l);
+  HIPCHK(hipGetLastError(), "kernel launch");
+  HIPCHK(hipMemcpyAsync(h_flag_, d_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "flag read");
+  stats_.launches = (int)prog_.launches.size() + 1;
+  return 0;
+}
+
+int Engine::factor_async_dev(const double* val_dev, int64_t nnz) {
+  if (status_) return status_;
+  if (nnz != S_->nnzA) return -10;
+  double t0 = now_ms();
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  HIPCHK(hipEventRecord(ev0_, stream_), "event");
+  if (val_dev != d_val_)
+    HIPCHK(hipMemcpyAsync(d_val_, val_dev, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, stream_), "val D2D");
+  HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
+  int rc = enqueue_program();
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev1_, stream_), "event");
+  pending_ = true;
+  stats_.submit_ms = now_ms() - t0;
+  return 0;
+}
+
+int Engine::factor_async(const double* val_host, int64_t nnz) {
+  if (status_) return status_;
+  if (nnz != S_->nnzA) return -10;
+  double t0 = now_ms();
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  HIPCHK(hipEventRecord(ev0_, stream_), "event");
+  HIPCHK(hipMemcpyAsync(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream_), "val H2D");
+  HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
+  int rc = enqueue_program();
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev1_, stream_), "event");
+  pending_ = true;
+  stats_.submit_ms = now_ms() - t0;
+  return 0;
+}
+
+int Engine::wait() {
+  if (status_) return status_;
+  if (!pending_) return 0;
+  HIPCHK(hipStreamSynchronize(stream_), "stream sync");
+  pending_ = false;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) stats_.device_ms = ms;
+  if (hipEventElapsedTime(&ms, ev0_, ev_h2d_) == hipSuccess) stats_.h2d_ms = ms;
+  npd_col_ = -1;
+  if (*h_flag_ != INT_MAX) {
+    npd_col_ = *h_flag_ - 1;
+    return kErrNotPosDef;
+  }
+  return 0;
+}
+
+int Engine::download(double* out, int64_t count) {
+  if (status_) return status_;
+  if (count > S_->arena) count = S_->arena;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  HIPCHK(hipMemcpy(out, d_L_, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost), "L D2H");
+  return 0;
+}
+
+int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms) {
+  if (status_) return status_;
+  if (nnz != S_->nnzA) return -10;
+  const Symbolic& S = *S_;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  HIPCHK(hipMemcpy(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice), "val H2D");
+  HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
+  *h_flag_ = INT_MAX;
+  HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
+  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, S.nnzA);
+  size_t nl = prog_.launches.size();
+  std::vector<hipEvent_t> ev(nl + 1);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e), "event create");
+  HIPCHK(hipEventRecord(ev[0], stream_), "event");
+  for (size_t i = 0; i < nl; ++i) {
+    enqueue_launch(prog_.launches[i]);
+    HIPCHK(hipEventRecord(ev[i + 1], stream_), "event");
+  }
+  HIPCHK(hipStreamSynchronize(stream_), "sync");
+  ms.assign(nl, 0.f);
+  for (size_t i = 0; i < nl; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  for (auto& e : ev) hipEventDestroy(e);
+  return 0;
+}
+
+}  // namespace spx

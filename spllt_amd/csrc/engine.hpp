@@ -1,0 +1,95 @@
+// Device-side factorization engine: owns the L arena in HBM, the uploaded
+// work tables of the stream-DAG program, and the HIP stream(s) it runs on.
+// This is what replaces spllt_stf_factorize + the task runtimes
+// (reference src/spllt_stf_mod.F90:18-192).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "schedule.hpp"
+#include "symbolic.hpp"
+
+namespace spx {
+
+struct EngineOptions {
+  int pw = 64;
+  int tile = 128;
+  bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
+};
+
+struct FactorStats {
+  double submit_ms = 0;   // host time spent in factor_async
+  double device_ms = 0;   // HIP-event time from first to last enqueued operation
+  double h2d_ms = 0;
+  int launches = 0;
+};
+
+class Engine {
+ public:
+  Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  int status() const { return status_; }  // 0 or SPLLT error flag from construction
+  const std::string& error() const { return err_; }
+
+  // spllt_factor: enqueue H2D of val, value scatter and the whole program.
+  int factor_async(const double* val_host, int64_t nnz);
+  // Same with val already resident in HBM (device pointer, same device).
+  int factor_async_dev(const double* val_dev, int64_t nnz);
+  // spllt_wait for this engine: drain the stream, surface "not positive definite".
+  int wait();
+  bool pending() const { return pending_; }
+  int not_posdef_column() const { return npd_col_; }
+
+  int download(double* out, int64_t count);  // D2H of the arena
+  double* device_L() { return d_L_; }
+  hipStream_t stream() { return stream_; }
+  const Program& program() const { return prog_; }
+  const Symbolic& symbolic() const { return *S_; }
+  const FactorStats& stats() const { return stats_; }
+  // per-launch device time of the last factorization (profiling mode)
+  int profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms);
+
+ private:
+  int upload();
+  int enqueue_program();
+  int enqueue_launch(const Launch& l);
+  int fail(int code, const char* what, hipError_t e);
+
+  std::shared_ptr<const Symbolic> S_;
+  EngineOptions opt_;
+  Program prog_;
+  int status_ = 0;
+  std::string err_;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t graph_exec_ = nullptr;
+  bool pending_ = false;
+  int npd_col_ = -1;
+  FactorStats stats_;
+
+  double* d_L_ = nullptr;
+  double* d_val_ = nullptr;
+  double* d_dinv_ = nullptr;
+  int64_t* d_map_dst_ = nullptr;
+  int64_t* d_map_src_ = nullptr;
+  int64_t* d_bc_off_ = nullptr;
+  int* d_bc_w_ = nullptr;
+  UpdUnit* d_units_ = nullptr;
+  UpdTile* d_tiles_ = nullptr;
+  PotrfUnit* d_potrf_ = nullptr;
+  int* d_relpos_ = nullptr;
+  int* d_rlist_ = nullptr;
+  int* d_flag_ = nullptr;
+  int* h_flag_ = nullptr;  // pinned
+};
+
+}  // namespace spx

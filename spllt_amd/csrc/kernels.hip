@@ -1,0 +1,393 @@
+// Hand-written CDNA4 (gfx950) kernels of the factorize hot path.
+//
+//   k_scatter_val   a8  spllt_init_node   (reference src/spllt_kernels_mod.F90:2301-2364)
+//   k_potrf_panel   a11 spllt_factor_diag_block (:1168-1189) on <=64-wide panels,
+//                   also emits the inverse of the factored panel for the TRSM
+//   k_update<T>     a12 spllt_solve_block (:1217) as X = A * inv(L_pp)^T,
+//                   a13 spllt_update_block (:1261-1292),
+//                   a16+a18 spllt_update_between + spllt_expand_buffer
+//                   (:2108-2237, :2010-2053) with the scatter fused into the
+//                   GEMM epilogue -- one fp64-MFMA kernel, three epilogues.
+//   k_scatter_block a26 spllt_scatter_block (:1122-1160) extend-add
+//
+// Storage convention: every block column of L is a
+// row-major (rows x width) matrix; all products are C = A * B^T with both
+// operands K-contiguous, which is exactly the operand order
+// v_mfma_f64_16x16x4_f64 wants: lane l supplies A[l&15][l>>4] and B[l>>4][l&15]
+// and receives C[(l>>4) + 4r][l&15] in register r.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace spx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// a8: L[dst[i]] = val[src[i]]  (assignment; the arena was zeroed beforehand)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_val(double* __restrict__ L,
+                                                     const double* __restrict__ val,
+                                                     const int64_t* __restrict__ dst,
+                                                     const int64_t* __restrict__ src, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) L[dst[i]] = val[src[i]];
+}
+
+// ---------------------------------------------------------------------------
+// a11: Cholesky of one <=64 x <=64 diagonal panel block per workgroup, in LDS,
+// plus X = L^-1 (lower triangular) written to the dinv scratch (row-major,
+// ld = n, strictly-upper part zero).  A non-positive pivot records
+// (pivot column + 1) in *flag (smallest wins) and leaves the block untouched
+// from that column on.
+// ---------------------------------------------------------------------------
+constexpr int PLD = 65;  // LDS row stride (doubles)
+
+__global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
+                                                     double* __restrict__ L,
+                                                     double* __restrict__ dinv,
+                                                     int* __restrict__ flag) {
+  __shared__ double T[64 * PLD];
+  __shared__ double X[64 * PLD];
+  __shared__ int s_fail;
+  const PotrfUnit u = units[blockIdx.x];
+  const int n = u.n, ld = u.ld, tid = threadIdx.x;
+  double* A = L + u.off;
+  if (tid == 0) s_fail = 0;
+  for (int idx = tid; idx < n * n; idx += 256) {
+    int i = idx / n, j = idx - i * n;
+    T[i * PLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
+    X[i * PLD + j] = 0.0;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  const bool do_chol = !(u.flags & 1);
+  for (int j = 0; do_chol && j < n; ++j) {
+    double d = T[j * PLD + j];
+    if (!(d > 0.0)) {  // uniform: every thread reads the same value
+      if (tid == 0) {
+        s_fail = 1;
+        atomicMin(flag, u.gcol + j + 1);
+      }
+      break;
+    }
+    d = sqrt(d);
+    const double rinv = 1.0 / d;
+    __syncthreads();
+    if (tid > j && tid < n) T[tid * PLD + j] *= rinv;
+    if (tid == j) T[j * PLD + j] = d;
+    __syncthreads();
+    for (int i = j + 1 + ty; i < n; i += 16) {
+      const double lij = T[i * PLD + j];
+      for (int k = j + 1 + tx; k <= i; k += 16) T[i * PLD + k] -= lij * T[k * PLD + j];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // write the factor back (lower triangle only)
+  for (int idx = tid; idx < n * n; idx += 256) {
+    int i = idx / n, j = idx - i * n;
+    if (do_chol && j <= i) A[(int64_t)i * ld + j] = T[i * PLD + j];
+  }
+  // inverse, one column per thread: X[:,c] solves L x = e_c
+  if (tid < n && !s_fail) {
+    const int c = tid;
+    X[c * PLD + c] = 1.0 / T[c * PLD + c];
+    for (int i = c + 1; i < n; ++i) {
+      double s = 0.0;
+      for (int k = c; k < i; ++k) s += T[i * PLD + k] * X[k * PLD + c];
+      X[i * PLD + c] = -s / T[i * PLD + i];
+    }
+  }
+  __syncthreads();
+  double* D = dinv + u.dinv_off;
+  for (int idx = tid; idx < n * n; idx += 256) {
+    int i = idx / n, j = idx - i * n;
+    D[idx] = X[i * PLD + j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The update kernel.  One workgroup (256 threads = 2x2 waves) owns one T x T
+// tile of one unit; each wave owns a (T/2)x(T/2) quadrant = FM x FM MFMA
+// fragments.  K is streamed in steps of 16 through LDS ([row][k], row stride 18
+// doubles -> conflict-free ds_read_b64 for the MFMA operand pattern) with the
+// next step's global loads issued before the current step's MFMAs.
+// ---------------------------------------------------------------------------
+constexpr int BK = 16;
+constexpr int LDK = 18;
+
+template <int T>
+__global__ __launch_bounds__(256) void k_update(const UpdTile* __restrict__ tiles,
+                                                const UpdUnit* __restrict__ units,
+                                                const int64_t* __restrict__ bc_off,
+                                                const int* __restrict__ bc_w,
+                                                double* __restrict__ L,
+                                                const int* __restrict__ relpos,
+                                                const int* __restrict__ rlist,
+                                                const double* __restrict__ dinv) {
+  constexpr int FM = T / 32;          // MFMA fragments per wave per dimension
+  constexpr int PER = T * BK / 256;   // doubles staged per thread per operand per step
+  constexpr int TPR = BK / PER;       // threads per tile row
+  __shared__ double As[T * LDK];
+  __shared__ double Bs[T * LDK];
+
+  const UpdTile tl = tiles[blockIdx.x];
+  const UpdUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = tl.ti * T, j0 = tl.tj * T;
+  const int M = u.M, N = u.N;
+
+  const int srow = tid / TPR;            // tile row staged by this thread
+  const int skof = (tid % TPR) * PER;    // first k of its chunk
+  const bool rowA_ok = (i0 + srow) < M;
+  const bool rowB_ok = (j0 + srow) < N;
+
+  d4 acc[FM][FM];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // ---- K-segment state -----------------------------------------------------
+  int seg = 0, kk = 0, klen = 0;
+  const double* aptr = nullptr;
+  const double* bptr = nullptr;
+  int64_t lda = 0, ldb = 0;
+  auto seg_setup = [&](int sg) {
+    const int bcol = u.src_bcol0 + sg;
+    const int w = bc_w[bcol];
+    const int64_t base = bc_off[bcol];
+    const int rshift = u.seg_r0 + sg * u.seg_stride;
+    const int kbeg = (u.nseg == 1) ? u.k0 : 0;
+    klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;
+    lda = w;
+    aptr = L + base + (int64_t)(u.src_r0 + i0 + srow - rshift) * w + kbeg + skof;
+    if (u.mode == MODE_TRSM) {
+      ldb = u.dinv_ld;
+      bptr = dinv + u.dinv_off + (int64_t)(j0 + srow) * ldb + skof;
+    } else if (u.b_bcol0 >= 0) {
+      const int bb = u.b_bcol0 + sg;
+      ldb = bc_w[bb];
+      bptr = L + bc_off[bb] +
+             (int64_t)(u.src_c0 + j0 + srow - (u.b_seg_r0 + sg * u.seg_stride)) * ldb + kbeg + skof;
+    } else {
+      ldb = w;
+      bptr = L + base + (int64_t)(u.src_c0 + j0 + srow - rshift) * w + kbeg + skof;
+    }
+  };
+  double ra[PER], rb[PER];
+  auto load_regs = [&]() {
+    const int kleft = klen - (kk + skof);  // valid elements in this thread's chunk
+    if (kleft >= PER) {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        ra[e] = rowA_ok ? aptr[kk + e] : 0.0;
+        rb[e] = rowB_ok ? bptr[kk + e] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        ra[e] = (rowA_ok && e < kleft) ? aptr[kk + e] : 0.0;
+        rb[e] = (rowB_ok && e < kleft) ? bptr[kk + e] : 0.0;
+      }
+    }
+  };
+
+  seg_setup(0);
+  while (klen <= 0 && seg + 1 < u.nseg) seg_setup(++seg);
+  bool more = klen > 0;
+  if (more) load_regs();
+
+  while (more) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      As[srow * LDK + skof + e] = ra[e];
+      Bs[srow * LDK + skof + e] = rb[e];
+    }
+    __syncthreads();
+    // advance to the next K step and start its global loads
+    kk += BK;
+    if (kk >= klen) {
+      more = false;
+      while (seg + 1 < u.nseg) {
+        seg_setup(++seg);
+        kk = 0;
+        if (klen > 0) { more = true; break; }
+      }
+    }
+    if (more) load_regs();
+    // MFMAs of the staged step
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double af[FM], bf[FM];
+      const int kq = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int a = 0; a < FM; ++a) af[a] = As[(wm * (T / 2) + a * 16 + (lane & 15)) * LDK + kq];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) bf[b] = Bs[(wn * (T / 2) + b * 16 + (lane & 15)) * LDK + kq];
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------
+  const int lr = lane >> 4, lc = lane & 15;
+  if (u.mode == MODE_SCATTER) {
+    // fused expand_buffer: dest[(relpos[i]-r0)*ld + (gcol[j]-c0)] -= acc
+    double* D = L + u.d_off;
+    int dcol[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      const int j = j0 + wn * (T / 2) + b * 16 + lc;
+      dcol[b] = (j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
+    }
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * (T / 2) + a * 16 + lr + 4 * r;
+        if (i >= M) continue;
+        const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          const int j = j0 + wn * (T / 2) + b * 16 + lc;
+          if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
+            unsafeAtomicAdd(D + drow + dcol[b], -acc[a][b][r]);
+        }
+      }
+  } else {
+    double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
+    const bool trsm = (u.mode == MODE_TRSM);
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * (T / 2) + a * 16 + lr + 4 * r;
+        if (i >= M) continue;
+        double* drow = D + (int64_t)i * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          const int j = j0 + wn * (T / 2) + b * 16 + lc;
+          if (j >= N) continue;
+          if (trsm) {
+            drow[j] = acc[a][b][r];
+          } else if (!u.lower || u.src_r0 + i >= u.src_c0 + j) {
+            drow[j] -= acc[a][b][r];
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a26: extend-add of a generated element window into an ancestor tile,
+// dest[pos_r(i)][pos_c(j)] -= src[i][j]; positions found by binary search in
+// the destination's (sorted) index lists.
+// ---------------------------------------------------------------------------
+__device__ inline int lower_bound_dev(const int* a, int n, int key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_block(int s_m, int s_n, const int* rsrc_index,
+                                                       const int* csrc_index, const double* src,
+                                                       int lds, const int* rdest_index, int d_m,
+                                                       const int* cdest_index, int d_n,
+                                                       double* dest, int ldd) {
+  const int64_t total = (int64_t)s_m * s_n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int sr = (int)(e / s_n), sc = (int)(e - (int64_t)sr * s_n);
+    const int dr = lower_bound_dev(rdest_index, d_m, rsrc_index[sr]);
+    const int dc = lower_bound_dev(cdest_index, d_n, csrc_index[sc]);
+    dest[(int64_t)dr * ldd + dc] -= src[(int64_t)sr * lds + sc];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a18 stand-alone: a[row_list[j]*blkn + col_list[i]] += buffer[j*cls + i],
+// i < (j < ndiag ? j+1 : cls).  One wavefront per buffer row: the buffer row is
+// read coalesced and consecutive col_list entries of one destination row are
+// near-contiguous.  Twin of
+// reference src/StarPU/expand_buffer_kernels.cu:27-45.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand_buffer(double* __restrict__ a, int blkn,
+                                                       const int* __restrict__ row_list, int rls,
+                                                       const int* __restrict__ col_list, int cls,
+                                                       int ndiag, const double* __restrict__ buffer) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwave = (gridDim.x * blockDim.x) >> 6;
+  for (int j = wave; j < rls; j += nwave) {
+    const int imax = j < ndiag ? j + 1 : cls;
+    double* arow = a + (int64_t)row_list[j] * blkn;
+    const double* b = buffer + (int64_t)j * cls;
+    for (int i = lane; i < imax; i += 64) arow[col_list[i]] += b[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (plain C++ callers do not see HIP launch syntax)
+// ---------------------------------------------------------------------------
+void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
+                          const int* col_list, int cls, int ndiag, const double* buffer) {
+  if (rls <= 0 || cls <= 0) return;
+  int blocks = (rls + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_expand_buffer, dim3(blocks), dim3(256), 0, st, a, blkn, row_list, rls,
+                     col_list, cls, ndiag, buffer);
+}
+
+void launch_scatter_val(hipStream_t st, double* L, const double* val, const int64_t* dst,
+                        const int64_t* src, int64_t n) {
+  if (n <= 0) return;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_scatter_val, dim3((unsigned)blocks), dim3(256), 0, st, L, val, dst, src, n);
+}
+
+void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
+                  int* flag) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+}
+
+void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
+                   const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
+                   const int* relpos, const int* rlist, const double* dinv) {
+  if (count <= 0) return;
+  if (tile == 128)
+    hipLaunchKernelGGL(k_update<128>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
+                       bc_off, bc_w, L, relpos, rlist, dinv);
+  else
+    hipLaunchKernelGGL(k_update<64>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
+                       bc_off, bc_w, L, relpos, rlist, dinv);
+}
+
+void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,
+                          const int* csrc_index, const double* src, int lds,
+                          const int* rdest_index, int d_m, const int* cdest_index, int d_n,
+                          double* dest, int ldd) {
+  int64_t total = (int64_t)s_m * s_n;
+  if (total <= 0) return;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_scatter_block, dim3((unsigned)blocks), dim3(256), 0, st, s_m, s_n,
+                     rsrc_index, csrc_index, src, lds, rdest_index, d_m, cdest_index, d_n, dest,
+                     ldd);
+}
+
+}  // namespace spx

@@ -1,0 +1,27 @@
+// Launch wrappers of the gfx950 kernels (kernels.hip).  Every wrapper only
+// enqueues work on `st`; none synchronises.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "schedule.hpp"
+
+namespace spx {
+
+void launch_scatter_val(hipStream_t st, double* L, const double* val, const int64_t* dst,
+                        const int64_t* src, int64_t n);
+void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
+                  int* flag);
+void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
+                   const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
+                   const int* relpos, const int* rlist, const double* dinv);
+void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,
+                          const int* csrc_index, const double* src, int lds,
+                          const int* rdest_index, int d_m, const int* cdest_index, int d_n,
+                          double* dest, int ldd);
+
+void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
+                          const int* col_list, int cls, int ndiag, const double* buffer);
+
+}  // namespace spx

@@ -1,0 +1,331 @@
+// Host-side construction of the batched stream-DAG program (see schedule.hpp).
+#include "schedule.hpp"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace spx {
+namespace {
+
+struct Builder {
+  const Symbolic& S;
+  const ScheduleOptions& opt;
+  Program& P;
+  int nb, pw;
+
+  Builder(const Symbolic& s, const ScheduleOptions& o, Program& p)
+      : S(s), opt(o), P(p), nb(s.nb), pw(std::min(o.pw, kPanelMax)) {}
+
+  static int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+  int pick_tile(int M, int N) const {
+    if (opt.tile <= 64) return 64;
+    return (M >= 96 && N >= 96) ? 128 : 64;
+  }
+
+  // Append the tiles of unit `u` (edge T); returns useful flops.
+  void add_tiles(std::vector<UpdTile>& out, int uid, const UpdUnit& u, int T, bool lower) {
+    int nti = cdiv(u.M, T), ntj = cdiv(u.N, T);
+    for (int tj = 0; tj < ntj; ++tj)
+      for (int ti = 0; ti < nti; ++ti) {
+        if (lower && u.src_r0 + (ti + 1) * T - 1 < u.src_c0 + tj * T) continue;
+        UpdTile t;
+        t.unit = uid;
+        t.ti = (short)ti;
+        t.tj = (short)tj;
+        out.push_back(t);
+      }
+  }
+
+  // Emit one GEMM phase: the units in `us` are split by tile size into at most
+  // two launches.
+  void emit_gemm(int level, std::vector<UpdUnit>& us, double flops, bool lower = true) {
+    if (us.empty()) return;
+    std::vector<UpdTile> t128, t64;
+    for (auto& u : us) {
+      int uid = (int)P.units.size();
+      P.units.push_back(u);
+      int T = (u.mode == MODE_TRSM) ? (u.N > 64 ? 128 : pick_tile(u.M, u.N)) : pick_tile(u.M, u.N);
+      add_tiles(T == 128 ? t128 : t64, uid, u, T, lower && u.lower);
+    }
+    double ntot = (double)t128.size() * 4 + (double)t64.size();
+    for (int pass = 0; pass < 2; ++pass) {
+      auto& tv = pass == 0 ? t128 : t64;
+      if (tv.empty()) continue;
+      Launch L;
+      L.kind = L_GEMM;
+      L.level = level;
+      L.first = (int64_t)P.tiles.size();
+      L.count = (int64_t)tv.size();
+      L.tile = pass == 0 ? 128 : 64;
+      L.flops = flops * ((double)tv.size() * (pass == 0 ? 4 : 1)) / std::max(1.0, ntot);
+      P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
+      P.launches.push_back(L);
+    }
+    us.clear();
+  }
+
+  bool mine(int s) const {
+    int own = opt.node_owner ? opt.node_owner[s] : -1;
+    if (opt.phase == 1) return own == opt.rank;
+    if (opt.phase == 2) return own < 0;
+    return own < 0 || own == opt.rank;
+  }
+
+  void run() {
+    P.pw = pw;
+    const int nn = S.nnodes;
+    int maxlevel = -1;
+    for (int s = 0; s < nn; ++s) maxlevel = std::max(maxlevel, S.level[s]);
+    std::vector<std::vector<int>> by_level(maxlevel + 1);
+    for (int s = 0; s < nn; ++s)
+      if (mine(s)) by_level[S.level[s]].push_back(s);
+
+    // dinv slots: one per (block column, panel)
+    std::vector<int64_t> dinv_slot(S.nbcol() + 1, 0);
+    {
+      int64_t o = 0;
+      for (int b = 0; b < S.nbcol(); ++b) {
+        dinv_slot[b] = o;
+        int w = S.bcols[b].width;
+        for (int c = 0; c < w; c += pw) {
+          int pn = std::min(pw, w - c);
+          o += (int64_t)pn * pn;
+        }
+      }
+      dinv_slot[S.nbcol()] = o;
+      P.dinv_size = o;
+    }
+
+    std::vector<UpdUnit> us;
+    for (int lev = 0; lev <= maxlevel; ++lev) {
+      const auto& nodes = by_level[lev];
+      if (nodes.empty()) continue;
+      int maxnc = 0;
+      for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
+      for (int c = 0; c < maxnc; ++c) {
+        int maxp = 0;
+        for (int s : nodes) {
+          int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+          if (c < nc) maxp = std::max(maxp, cdiv(S.bcols[S.node_bcol0[s] + c].width, pw));
+        }
+        for (int p = 0; p < maxp; ++p) {
+          // (1) left-looking update of panel p by the previous panels of the block column
+          double fl = 0;
+          if (p > 0) {
+            for (int s : nodes) {
+              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              int c0 = p * pw;
+              if (c0 >= B.width) continue;
+              int pn = std::min(pw, B.width - c0);
+              UpdUnit u{};
+            u.b_bcol0 = -1;
+            u.lower = 1;
+              u.mode = MODE_DIRECT;
+              u.d_off = B.off;
+              u.d_ld = B.width;
+              u.d_row0 = c0;
+              u.d_col0 = c0;
+              u.src_bcol0 = b;
+              u.nseg = 1;
+              u.seg_r0 = B.r0;
+              u.seg_stride = nb;
+              u.src_r0 = B.r0 + c0;
+              u.src_c0 = B.r0 + c0;
+              u.M = B.nrow - c0;
+              u.N = pn;
+              u.k0 = 0;
+              u.klen = c0;
+              us.push_back(u);
+              fl += 2.0 * c0 * ((double)u.M * pn - 0.5 * pn * (pn - 1));
+            }
+            P.flops_update += fl;
+            emit_gemm(lev, us, fl);
+          }
+          // (2) POTRF of the diagonal panel blocks
+          {
+            Launch L;
+            L.kind = L_POTRF;
+            L.level = lev;
+            L.first = (int64_t)P.potrf_units.size();
+            L.tile = 0;
+            fl = 0;
+            for (int s : nodes) {
+              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              int c0 = p * pw;
+              if (c0 >= B.width) continue;
+              int pn = std::min(pw, B.width - c0);
+              PotrfUnit q{};
+              q.off = B.off + (int64_t)c0 * B.width + c0;
+              q.ld = B.width;
+              q.n = pn;
+              q.gcol = S.sptr[s] + B.r0 + c0;
+              int64_t slot = dinv_slot[b];
+              for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
+              q.dinv_off = slot;
+              P.potrf_units.push_back(q);
+              fl += (double)pn * pn * pn / 3.0;
+            }
+            L.count = (int64_t)P.potrf_units.size() - L.first;
+            L.flops = fl;
+            P.flops_potrf += fl;
+            if (L.count > 0) P.launches.push_back(L);
+          }
+          // (3) TRSM of the rows below the panel: X = A * inv(Lpp)^T (in place)
+          fl = 0;
+          for (int s : nodes) {
+            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c >= nc) continue;
+            int b = S.node_bcol0[s] + c;
+            const BlockCol& B = S.bcols[b];
+            int c0 = p * pw;
+            if (c0 >= B.width) continue;
+            int pn = std::min(pw, B.width - c0);
+            int rows = B.nrow - (c0 + pn);
+            if (rows <= 0) continue;
+            UpdUnit u{};
+            u.b_bcol0 = -1;
+            u.lower = 1;
+            u.mode = MODE_TRSM;
+            u.lower = 0;
+            u.d_off = B.off;
+            u.d_ld = B.width;
+            u.d_row0 = c0 + pn;
+            u.d_col0 = c0;
+            u.src_bcol0 = b;
+            u.nseg = 1;
+            u.seg_r0 = B.r0;
+            u.seg_stride = nb;
+            u.src_r0 = B.r0 + c0 + pn;
+            u.src_c0 = 0;
+            u.M = rows;
+            u.N = pn;
+            u.k0 = c0;
+            u.klen = pn;
+            int64_t slot = dinv_slot[b];
+            for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
+            u.dinv_off = slot;
+            u.dinv_ld = pn;
+            us.push_back(u);
+            fl += (double)rows * pn * pn;
+          }
+          P.flops_trsm += fl;
+          emit_gemm(lev, us, fl, false);
+        }
+        // (4) right-looking update of the node's later block columns, K = blkn
+        double fl = 0;
+        for (int s : nodes) {
+          int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+          if (c + 1 >= nc) continue;
+          int b = S.node_bcol0[s] + c;
+          const BlockCol& B = S.bcols[b];
+          for (int jj = c + 1; jj < nc; ++jj) {
+            const BlockCol& D = S.bcols[S.node_bcol0[s] + jj];
+            UpdUnit u{};
+            u.b_bcol0 = -1;
+            u.lower = 1;
+            u.mode = MODE_DIRECT;
+            u.d_off = D.off;
+            u.d_ld = D.width;
+            u.d_row0 = 0;
+            u.d_col0 = 0;
+            u.src_bcol0 = b;
+            u.nseg = 1;
+            u.seg_r0 = B.r0;
+            u.seg_stride = nb;
+            u.src_r0 = D.r0;
+            u.src_c0 = D.r0;
+            u.M = D.nrow;
+            u.N = D.width;
+            u.k0 = 0;
+            u.klen = B.width;
+            us.push_back(u);
+            fl += 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+          }
+        }
+        P.flops_update += fl;
+        emit_gemm(lev, us, fl);
+      }
+      // (5) inter-node updates of the whole level (update_between + scatter)
+      double fl = 0;
+      for (int s : nodes) {
+        const int m = S.nrow(s), ncol = S.ncol(s);
+        const int* idx = S.rows(s);
+        int cptr = ncol;
+        int a = S.sparent[s];
+        while (a < nn && cptr < m) {
+          const int asa = S.sptr[a], aen = S.sptr[a + 1] - 1;
+          while (cptr < m && idx[cptr] < asa) cptr++;
+          if (cptr >= m) break;
+          if (idx[cptr] <= aen) {
+            // positions of rows cptr..m-1 of s inside a's row list
+            const int* aidx = S.rows(a);
+            const int am = S.nrow(a);
+            int64_t base = (int64_t)P.relpos.size();
+            {
+              int q = 0;
+              for (int r = cptr; r < m; ++r) {
+                while (q < am && aidx[q] < idx[r]) q++;
+                if (q >= am || aidx[q] != idx[r]) {
+                  std::fprintf(stderr, "spllt-hip: structure inclusion violated (node %d -> %d)\n", s, a);
+                  q = std::min(q, am - 1);
+                }
+                P.relpos.push_back(q);
+              }
+            }
+            const int first = cptr;
+            while (cptr < m && idx[cptr] <= aen) {
+              int cb = (idx[cptr] - asa) / nb;
+              int jlast = std::min(asa + (cb + 1) * nb - 1, aen);
+              int cptr2 = cptr;
+              while (cptr2 + 1 < m && idx[cptr2 + 1] <= jlast) cptr2++;
+              const BlockCol& D = S.bcols[S.node_bcol0[a] + cb];
+              UpdUnit u{};
+            u.b_bcol0 = -1;
+            u.lower = 1;
+              u.mode = MODE_SCATTER;
+              u.d_off = D.off;
+              u.d_ld = D.width;
+              u.d_row0 = D.r0;
+              u.d_col0 = asa + cb * nb;
+              u.relrow_off = base + (cptr - first);
+              u.gcol_off = S.rptr[s] + cptr;
+              u.src_bcol0 = S.node_bcol0[s];
+              u.nseg = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              u.seg_r0 = 0;
+              u.seg_stride = nb;
+              u.src_r0 = cptr;
+              u.src_c0 = cptr;
+              u.M = m - cptr;
+              u.N = cptr2 - cptr + 1;
+              u.k0 = 0;
+              u.klen = -1;
+              us.push_back(u);
+              fl += 2.0 * ncol * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+              cptr = cptr2 + 1;
+            }
+          }
+          a = S.sparent[a];
+        }
+      }
+      P.flops_between += fl;
+      emit_gemm(lev, us, fl);
+    }
+  }
+};
+
+}  // namespace
+
+void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {
+  P = Program();
+  Builder b(S, opt, P);
+  b.run();
+}
+
+}  // namespace spx

@@ -1,0 +1,103 @@
+// Stream-DAG program of one factorization: the host-side replacement for
+// SpLLT's task submission layer (reference src/spllt_factorization_mod.F90:474-751
+// and src/spllt_factorization_task_mod.F90).  Instead of one runtime task per
+// tile kernel, the elimination tree is cut into levels and every level is a
+// short sequence of *batched* launches whose work lists live in device memory:
+//
+//   per level, per block-column step c, per inner panel p (width <= PW):
+//       POTRF  : diagonal panel blocks      (factorize_block, kernels_mod:1168)
+//       TRSM   : rows below each panel      (solve_block,     kernels_mod:1217)
+//       UPDATE : rest of the block column   (update_block,    kernels_mod:1261)
+//     UPDATE   : trailing block columns of the same node with K = blkn
+//   UPDATE/scatter: every (node, ancestor block column) pair of the level
+//                (update_between + expand_buffer, kernels_mod:2108, :2010)
+//
+// Everything here is plain C++ (no HIP) so that it can be unit-tested on CPU.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "symbolic.hpp"
+
+namespace spx {
+
+constexpr int kPanelMax = 64;  // widest diagonal panel the POTRF kernel accepts
+
+enum UnitMode : int { MODE_DIRECT = 0, MODE_SCATTER = 1, MODE_TRSM = 2 };
+
+// One batched-GEMM work unit:   C[rowmap(i)][colmap(j)] (-)= sum_seg A_seg[i][:] . B_seg[j][:]
+// A rows are node-local rows [src_r0, src_r0+M) of the source supernode, B rows
+// are [src_c0, src_c0+N); K runs over `nseg` consecutive block columns of the
+// source (or over columns [k0, k0+klen) of a single one).  Only entries with
+// src_r0+i >= src_c0+j (the lower triangle in source-row terms) are written.
+struct UpdUnit {
+  int64_t d_off;       // arena offset of the destination block column
+  int64_t relrow_off;  // SCATTER: offset into relpos[] of the entry for i = 0
+  int64_t gcol_off;    // SCATTER: offset into rlist[] of the entry for j = 0
+  int64_t dinv_off;    // TRSM: offset of the inverted diagonal panel in the dinv scratch
+  int src_bcol0;       // first source block column (global id)
+  int nseg;            // number of source block columns (K segments)
+  int seg_r0;          // node-local row of the first stored row of segment 0
+  int seg_stride;      // nb (each following segment starts nb rows lower)
+  int src_r0, src_c0;  // node-local first A / B row
+  int M, N;
+  int k0, klen;        // nseg == 1: column window inside the block column (klen < 0: all)
+  int d_ld;            // destination row width
+  int d_row0;          // DIRECT/TRSM: stored row of i = 0;  SCATTER: node-local r0 of dest bcol
+  int d_col0;          // DIRECT/TRSM: column of j = 0;      SCATTER: pivot position of dest col 0
+  int mode;
+  int dinv_ld;
+  int lower;           // 1: write only entries with src_r0+i >= src_c0+j
+  int b_bcol0;         // >= 0: B rows come from this block column (else same as A)
+  int b_seg_r0;        // node-local row of the first stored row of B's segment 0
+  int pad_;
+};
+
+struct UpdTile {
+  int unit;
+  short ti, tj;
+};
+
+struct PotrfUnit {
+  int64_t off;       // arena offset of the panel's (0,0) entry
+  int64_t dinv_off;  // where the inverse of the factored panel goes
+  int ld;            // row width of the block column
+  int n;             // panel order (<= kPanelMax)
+  int gcol;          // pivot position of the panel's first column (error reporting)
+  int flags;         // bit 0: block is already a Cholesky factor, only invert it
+};
+
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1 };
+
+struct Launch {
+  int kind;
+  int level;
+  int64_t first, count;  // range in potrf_units (L_POTRF) or tiles (L_GEMM)
+  int tile;              // L_GEMM: tile edge (128 or 64 ...)
+  double flops;          // useful flops of this launch (for reporting)
+};
+
+struct Program {
+  int pw = 64;  // inner panel width
+  std::vector<PotrfUnit> potrf_units;
+  std::vector<UpdUnit> units;
+  std::vector<UpdTile> tiles;
+  std::vector<Launch> launches;
+  std::vector<int> relpos;      // per (node, touched ancestor): positions of the node's rows in the ancestor's row list
+  int64_t dinv_size = 0;        // doubles
+  double flops_potrf = 0, flops_trsm = 0, flops_update = 0, flops_between = 0;
+};
+
+struct ScheduleOptions {
+  int pw = 64;          // inner panel width (<= kPanelMax)
+  int tile = 128;       // GEMM tile edge for large units
+  int rank = 0;         // multi-GPU: build only this rank's part ...
+  int nranks = 1;       // ... of the subtree partition
+  const int* node_owner = nullptr;  // nnodes: owning rank, or -1 = replicated (top tree)
+  int phase = 0;        // 0 = everything owned/replicated in one program;
+                        // 1 = only nodes owned by `rank`; 2 = only replicated nodes
+};
+
+void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);
+
+}  // namespace spx

@@ -1,0 +1,91 @@
+"""Numpy interpreter of the stream-DAG program exported by
+spllt_hip_program_get.  TEST-ONLY: it executes the same work tables the HIP
+kernels consume (potrf units, update units, tiles, launches) with dense numpy
+arithmetic, so that the host-side scheduler can be validated on a machine
+without a GPU.  It is not part of the product and is never timed."""
+import numpy as np
+import scipy.linalg as sl
+
+MODE_DIRECT, MODE_SCATTER, MODE_TRSM = 0, 1, 2
+
+
+def emulate_program(f, val):
+    info = f.sym_info()
+    arena = np.zeros(info["arena"])
+    md, ms = f.sym("map_dst"), f.sym("map_src")
+    arena[md] = np.asarray(val)[ms]
+    launches = f.program("launches")
+    potrf = f.program("potrf")
+    units = f.program("units")
+    tiles = f.program("tiles")
+    relpos = f.program("relpos")
+    rlist = f.sym("rlist")
+    bc_off, bc_w = f.sym("bcol_off"), f.sym("bcol_width")
+    dinv = np.zeros(max(1, f.program("dinv_size")))
+
+    def seg_rows(u, sg, r0, cnt, from_b):
+        """rows [r0, r0+cnt) x K-window of segment sg as a dense (cnt x klen) array"""
+        if from_b and u["b_bcol0"] >= 0:
+            bcol = int(u["b_bcol0"]) + sg
+            rshift = int(u["b_seg_r0"]) + sg * int(u["seg_stride"])
+        else:
+            bcol = int(u["src_bcol0"]) + sg
+            rshift = int(u["seg_r0"]) + sg * int(u["seg_stride"])
+        w = int(bc_w[bcol])
+        kbeg = int(u["k0"]) if u["nseg"] == 1 else 0
+        klen = int(u["klen"]) if (u["nseg"] == 1 and u["klen"] >= 0) else w
+        base = int(bc_off[bcol])
+        out = np.empty((cnt, klen))
+        for i in range(cnt):
+            s = base + (r0 + i - rshift) * w + kbeg
+            out[i] = arena[s:s + klen]
+        return out
+
+    for kind, level, first, count, tile, _ in launches:
+        if kind == 0:
+            for q in potrf[first:first + count]:
+                n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])
+                idx = off + np.arange(n)[:, None] * ld + np.arange(n)[None, :]
+                blk = np.tril(arena[idx])
+                Lb = blk if (q["flags"] & 1) else sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
+                if not (q["flags"] & 1):
+                    low = np.tril_indices(n)
+                    arena[idx[low]] = Lb[low]
+                X = sl.solve_triangular(Lb, np.eye(n), lower=True)
+                dinv[int(q["dinv_off"]):int(q["dinv_off"]) + n * n] = X.ravel()
+            continue
+        T = int(tile)
+        for t in tiles[first:first + count]:
+            u = units[int(t["unit"])]
+            i0, j0 = int(t["ti"]) * T, int(t["tj"]) * T
+            mi, nj = min(T, int(u["M"]) - i0), min(T, int(u["N"]) - j0)
+            assert mi > 0 and nj > 0
+            P = np.zeros((mi, nj))
+            for sg in range(int(u["nseg"])):
+                Ablk = seg_rows(u, sg, int(u["src_r0"]) + i0, mi, False)
+                if u["mode"] == MODE_TRSM:
+                    n = int(u["dinv_ld"])
+                    X = dinv[int(u["dinv_off"]):int(u["dinv_off"]) + n * n].reshape(n, n)
+                    Bblk = X[j0:j0 + nj, :Ablk.shape[1]]
+                else:
+                    Bblk = seg_rows(u, sg, int(u["src_c0"]) + j0, nj, True)
+                P += Ablk @ Bblk.T
+            ii = np.arange(mi)[:, None] + i0
+            jj = np.arange(nj)[None, :] + j0
+            keep = np.ones((mi, nj), dtype=bool)
+            if u["lower"]:
+                keep = (int(u["src_r0"]) + ii) >= (int(u["src_c0"]) + jj)
+            if u["mode"] == MODE_SCATTER:
+                dr = relpos[int(u["relrow_off"]) + ii] - int(u["d_row0"])
+                dc = rlist[int(u["gcol_off"]) + jj] - int(u["d_col0"])
+                assert (dr[keep.any(axis=1)] >= 0).all() and (dc >= 0).all() and (dc < u["d_ld"]).all()
+                idx = int(u["d_off"]) + dr * int(u["d_ld"]) + dc
+                np.subtract.at(arena, idx[keep], P[keep])
+            else:
+                idx = (int(u["d_off"]) + (int(u["d_row0"]) + ii) * int(u["d_ld"]) +
+                       int(u["d_col0"]) + jj)
+                if u["mode"] == MODE_TRSM:
+                    arena[idx] = P
+                else:
+                    arena[idx[keep]] -= P[keep]
+    return arena

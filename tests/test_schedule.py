@@ -1,0 +1,116 @@
+"""CPU tests of the host side of the product: analyse stand-in (orderings,
+supernodes, tiling) and the stream-DAG program (work tables), the latter by
+interpreting the exported tables in numpy (tests/emulate.py) and comparing
+with the oracle / a dense Cholesky."""
+import numpy as np
+import pytest
+
+from emulate import emulate_program
+from helpers import dense_arena, lower_mask, make_case, oracle_factor, rel_err
+from spllt_amd import matgen
+
+CASES = [
+    ("p2d12-nb4", lambda: matgen.poisson2d(12), 4, 4, 64),
+    ("p2d16-nb8", lambda: matgen.poisson2d(16), 8, 4, 64),
+    ("p2d24-nb200", lambda: matgen.poisson2d(24), 200, 32, 64),
+    ("p3d6-nb8", lambda: matgen.poisson3d(6), 8, 4, 64),
+    ("box6-nb96-pw32", lambda: matgen.nd_like((6, 6, 6), 2), 96, 8, 32),
+    ("box7-nb256", lambda: matgen.nd_like((7, 7, 6), 2), 256, 16, 64),
+]
+
+
+@pytest.mark.parametrize("name,gen,nb,nemin,pw", CASES)
+def test_program_tables_reproduce_oracle(name, gen, nb, nemin, pw):
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw)
+    got = emulate_program(f, val)
+    o, rc = oracle_factor(f, val)
+    assert rc == 0
+    mask = lower_mask(f)
+    assert rel_err(got, o.arena(), mask) < 1e-13
+    assert rel_err(got, dense_arena(f, A), mask) < 1e-13
+    # strictly-upper triangle of diagonal tiles is never written by the program
+    assert np.all(got[~mask] == 0.0)
+
+
+@pytest.mark.parametrize("gen", [lambda: matgen.poisson2d(20), lambda: matgen.poisson3d(7),
+                                 lambda: matgen.nd_like((8, 7, 6), 2),
+                                 lambda: matgen.fe27((4, 4, 3), 3)])
+@pytest.mark.parametrize("use_geo", [False, True])
+def test_symbolic_structure_is_valid(gen, use_geo):
+    """order is a permutation, nodes are postordered, row lists are sorted,
+    own columns first, and contain the pattern of A and of the children."""
+    A = gen()
+    order = None
+    f, val = make_case(A, nb=16, nemin=8, order=order)
+    n = f.n
+    o = f.sym("order")
+    assert sorted(o.tolist()) == list(range(n))
+    sptr, sparent, rptr, rlist = f.sym("sptr"), f.sym("sparent"), f.sym("rptr"), f.sym("rlist")
+    nn = len(sparent)
+    assert sptr[0] == 0 and sptr[-1] == n
+    Ap = A.tocsc()
+    for s in range(nn):
+        assert sparent[s] > s
+        rows = rlist[rptr[s]:rptr[s + 1]]
+        nc = sptr[s + 1] - sptr[s]
+        assert (rows[:nc] == np.arange(sptr[s], sptr[s + 1])).all()
+        assert (np.diff(rows) > 0).all()
+        p = sparent[s]
+        if p < nn:
+            prow = set(rlist[rptr[p]:rptr[p + 1]].tolist())
+            assert set(rows[nc:].tolist()) <= prow
+    inv = np.empty(n, dtype=np.int64)
+    inv[o] = np.arange(n)
+    snode = np.repeat(np.arange(nn), np.diff(sptr))
+    for j in range(n):
+        for i in Ap.indices[Ap.indptr[j]:Ap.indptr[j + 1]]:
+            a, b = sorted((o[i], o[j]))
+            s = snode[a]
+            assert b in set(rlist[rptr[s]:rptr[s + 1]].tolist())
+    info = f.sym_info()
+    m = np.diff(rptr)
+    ncol = np.diff(sptr)
+    nnzl = sum(int(mm - c + j) for mm, c in zip(m, ncol) for j in range(1, c + 1))
+    flops = sum(int(mm - c + j) ** 2 for mm, c in zip(m, ncol) for j in range(1, c + 1))
+    assert info["nnz_l"] == nnzl and info["flops"] == flops
+
+
+def test_user_order_is_honoured_up_to_postorder():
+    A = matgen.poisson2d(16)
+    geo = matgen.geometric_nd_order((16, 16))
+    f, val = make_case(A, nb=16, nemin=4, order=geo)
+    assert f.sym_info()["ordering"] == "user"
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+def test_prune_tree_marks():
+    """spllt_prune_tree restated (analyse_mod:806-987): ncpu=1 turns every tree
+    root with its whole subtree into one pruned subtree (SURVEY 3.1 trap);
+    ncpu>1 leaves a top tree with small==0."""
+    A = matgen.poisson2d(32)
+    f1, _ = make_case(A, nb=32, nemin=16, prune=True, ncpu=1)
+    small, sparent = f1.sym("small"), f1.sym("sparent")
+    nn = len(sparent)
+    roots = [s for s in range(nn) if sparent[s] == nn]
+    assert all(small[r] == 1 for r in roots)
+    assert all(small[s] == 1 or small[s] < 0 for s in range(nn))
+    f4, _ = make_case(A, nb=32, nemin=16, prune=True, ncpu=4)
+    small = f4.sym("small")
+    assert (small == 0).sum() >= 1 and (small == 1).sum() >= 4
+    # members of a subtree point at its root, which is an ancestor
+    for s in range(nn):
+        if small[s] < 0:
+            r = -small[s] - 1
+            a = s
+            while a != r and a < nn:
+                a = f4.sym("sparent")[a] if False else sparent_of(f4, a)
+            assert a == r
+
+
+def sparent_of(f, a, _cache={}):
+    key = id(f)
+    if key not in _cache:
+        _cache[key] = f.sym("sparent")
+    return int(_cache[key][a])
