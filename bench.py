@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: factorize GFLOP/s (fp64) of the MI355X engine.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete numerical factorization (spllt_factor -> spllt_wait,
+reference timing window drivers/spllt_omp.F90:185-192) of the workload, with
+`val` already resident in HBM and L left device-resident.  GFLOP/s = F_sym / t
+with F_sym the reference's own symbolic flop count
+(src/spllt_analyse_mod.F90:1007-1023).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X vendor fp64 matrix peak (dense); see DESIGN.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="nd24k_like", help="matgen.CONFIGS key")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink every grid edge (debug)")
+    ap.add_argument("--mm", default=None, help="MatrixMarket file to use instead of the stand-in")
+    ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"])
+    ap.add_argument("--nb", type=int, default=None)
+    ap.add_argument("--panel", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--profile-out", default=None, help="write the per-launch timing table here")
+    return ap.parse_args()
+
+
+def build_workload(args):
+    from spllt_amd import api, matgen
+    if args.mm:
+        A = matgen.make_diag_dominant(matgen.read_mtx(args.mm))
+        order, cfg = None, dict(nb=args.nb or 256, gen="mtx:" + os.path.basename(args.mm))
+        name = "mtx:" + os.path.basename(args.mm)
+    else:
+        A, order, cfg = matgen.build_config(args.config, args.scale)
+        name = args.config + ("" if args.scale == 1.0 else f"@{args.scale}")
+        if args.ordering == "builtin":
+            order = None
+    nb = args.nb or cfg["nb"]
+    n, ptr, row, val = api.csc_lower_1based(A)
+    return A, n, ptr, row, val, order, nb, name, cfg
+
+
+def roofline_from_profile(f, val):
+    """Dominant kernel = k_update<128> (fp64 MFMA GEMM with direct / scatter
+    epilogue).  achieved = algorithmic flops of all its launches / the sum of
+    their durations, measured with HIP events on the engine's own stream."""
+    ms = f.profile(val)
+    L = f.program("launches")
+    kinds, tiles, flops = L[:, 0], L[:, 4], L[:, 5].astype(np.float64)
+    sel = (kinds == 1) & (tiles == 128)
+    t128 = float(ms[sel].sum()) * 1e-3
+    fl128 = float(flops[sel].sum())
+    table = {
+        "potrf_ms": float(ms[kinds == 0].sum()), "potrf_launches": int((kinds == 0).sum()),
+        "update128_ms": float(ms[sel].sum()), "update128_launches": int(sel.sum()),
+        "update64_ms": float(ms[(kinds == 1) & (tiles == 64)].sum()),
+        "update64_launches": int(((kinds == 1) & (tiles == 64)).sum()),
+        "total_ms": float(ms.sum()),
+        "update128_gflop": fl128 / 1e9, "total_gflop": float(flops.sum()) / 1e9,
+    }
+    ach = fl128 / t128 / 1e12 if t128 > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "k_update<128>", "achieved": round(ach, 3),
+            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": int(sel.sum()),
+            "avg_launch_ms": round(float(ms[sel].mean()) if sel.any() else 0.0, 4)}
+    return roof, table, ms
+
+
+def cpu_baseline(f, val, flops, threads):
+    """The oracle (CPU restatement on MKL + OpenMP tasks with the reference's
+    dependency tokens) on the SAME workload, timed on this host's cores."""
+    from oracle import pyoracle
+    try:
+        o = pyoracle.OracleFactor.from_factorization(f, variant="mkl")
+        blas = "mkl"
+    except Exception:
+        o = pyoracle.OracleFactor.from_factorization(f, variant="plain")
+        blas, threads = "plain-c", 1
+    t0 = time.time()
+    rc = o.factorize(val, threads)
+    dt = time.time() - t0
+    return o, {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads,
+               "kind": "port", "seconds": round(dt, 3), "blas": blas, "rc": rc}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    from spllt_amd import api
+    A, n, ptr, row, val, order, nb, name, cfg = build_workload(args)
+
+    if world > 1:
+        from spllt_amd import multigpu
+        out = multigpu.bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    t0 = time.time()
+    f = api.Factorization(n, ptr, row, nb=nb, nemin=32, prune_tree=False, order=order,
+                          panel_width=args.panel)
+    t_analyse = time.time() - t0
+    si = f.sym_info()
+    flops = float(si["flops"])
+    dval = torch.tensor(val, device="cuda")
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        f.factor_dev(dval.data_ptr()).wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(args.steps):
+        f.factor_dev(dval.data_ptr()).wait()
+        dev_ms.append(f.times()["device_ms"])
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    ms_per_step = t_total / args.steps * 1e3
+    value = flops / (t_total / args.steps) / 1e9
+
+    # drop-in variant (H2D of val + D2H of L), reported separately, never `value`
+    t0 = time.perf_counter()
+    f.factor(val).wait()
+    t_h2d = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    L = f.get_factor()
+    t_d2h = time.perf_counter() - t0
+
+    check = {}
+    if not args.no_check:
+        b = A @ np.ones(n)
+        x = f.solve(b)
+        r = b - A @ x
+        check = {"resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
+                 "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
+
+    roof, table, ms = roofline_from_profile(f, val)
+    if args.profile_out:
+        Lh = f.program("launches")
+        with open(args.profile_out, "w") as fh:
+            fh.write("idx kind level count tile gflop ms\n")
+            for i, (l, m) in enumerate(zip(Lh, ms)):
+                fh.write(f"{i} {l[0]} {l[1]} {l[3]} {l[4]} {l[5] / 1e9:.4f} {m:.4f}\n")
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+        o, cpu = cpu_baseline(f, val, flops, threads)
+        cpu["sample"] = f"full workload ({name}, {flops / 1e9:.0f} GFLOP), one factorization"
+        if not args.no_check:
+            ref = o.arena()
+            check["max_relerr_L_vs_cpu"] = float(np.abs(L - ref).max() / np.abs(ref).max())
+
+    out = {
+        "metric": "factorize GFLOP/s (fp64)", "value": round(value, 2), "unit": "GFLOP/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": name, "stand_in_for": "SuiteSparse ND/nd24k" if "nd24k" in name else None,
+                   "n": n, "nnz_lower": int(si["nnz_a"]), "nb": nb, "nnz_L": int(si["nnz_l"]),
+                   "flops_sym": flops, "nnodes": int(si["nnodes"]), "ordering": si["ordering"] + ("/geometric-nd" if order is not None else ""),
+                   "parallelism": "1 GPU, level-batched stream DAG"},
+        "roofline": roof, "cpu_baseline": cpu,
+        "detail": {"device_ms_per_step": round(float(np.mean(dev_ms)), 3), "analyse_s": round(t_analyse, 2),
+                   "dropin_factor_s": round(t_h2d, 4), "L_d2h_s": round(t_d2h, 4),
+                   "launches": f.times()["launches"], "kernel_table": table, "check": check},
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

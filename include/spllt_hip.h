@@ -92,8 +92,9 @@ int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
  * "lmap_ptr", "weight". */
 int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_t capacity);
 
-/* engine knobs (before the first spllt_factor on this fkeep) */
-int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int use_graph);
+/* engine knobs (before the first spllt_factor on this fkeep); flags: bit 0 =
+ * replay through a hipGraph, bit 1 = single-stream program (no lookahead) */
+int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 
 /* spllt_factor with val already resident in HBM (device pointer) */
 void spllt_hip_factor_dev(void *akeep, void *fkeep, spllt_options_t *options, int nnz,
@@ -107,8 +108,8 @@ double *spllt_hip_device_factor(void *fkeep);
 /* timings of the last factorization, milliseconds */
 int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, double *h2d_ms,
                            int *launches);
-/* program export for tests: "launches" (int64 x 6 per launch: kind, level,
- * first, count, tile, flops), "potrf" (PotrfUnit bytes), "units" (UpdUnit
+/* program export for tests: "launches" (int64 x 10 per launch: kind, level,
+ * first, count, tile, flops, stream, wait0, wait1, record), "potrf" (PotrfUnit bytes), "units" (UpdUnit
  * bytes), "tiles" (UpdTile bytes), "relpos" (int32).  Returns byte length. */
 int64_t spllt_hip_program_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 /* per-launch device time (ms) of one profiled factorization; returns #launches */

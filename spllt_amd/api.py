@@ -59,7 +59,7 @@ class Factorization:
     """One analysed pattern: owns the akeep/fkeep handle pair."""
 
     def __init__(self, n, ptr, row, nb=256, nemin=32, prune_tree=True, ncpu=1, order=None,
-                 panel_width=None, tile=None):
+                 panel_width=None, tile=None, engine_flags=0):
         self.lib = _lib.load()
         self.n = int(n)
         self.ptr = np.ascontiguousarray(ptr, dtype=np.int32)
@@ -86,8 +86,8 @@ class Factorization:
                                                _ip(oin))
         if self.info.flag < 0:
             raise SplltError("spllt_analyse", self.info.flag)
-        if panel_width or tile:
-            self.lib.spllt_hip_set_engine(self.fkeep, panel_width or 0, tile or 0, 0)
+        if panel_width or tile or engine_flags:
+            self.lib.spllt_hip_set_engine(self.fkeep, panel_width or 0, tile or 0, engine_flags)
         self._val_keepalive = None
 
     # ---- symbolic introspection ------------------------------------------
@@ -119,7 +119,7 @@ class Factorization:
         self.lib.spllt_hip_program_get(self.fkeep, name.encode(), raw.ctypes.data, nbytes)
         raw = raw[:nbytes]
         if name == "launches":
-            return raw.view(np.int64).reshape(-1, 6)
+            return raw.view(np.int64).reshape(-1, 10)
         if name == "units":
             return raw.view(UPD_UNIT_DTYPE)
         if name == "tiles":

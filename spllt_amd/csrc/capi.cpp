@@ -448,7 +448,8 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) 
   if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
   if (panel_width > 0) f->eo.pw = std::min(panel_width, kPanelMax);
   if (tile > 0) f->eo.tile = tile;
-  f->eo.use_graph = use_graph != 0;
+  f->eo.use_graph = (use_graph & 1) != 0;
+  f->eo.lookahead = (use_graph & 2) == 0;  // bit 1 set: single-stream program
   return 0;
 }
 
@@ -489,6 +490,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     ScheduleOptions so;
     so.pw = f->eo.pw;
     so.tile = f->eo.tile;
+    so.lookahead = f->eo.lookahead;
     build_program(*f->S, so, local);
     P = &local;
   }
@@ -502,6 +504,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     for (const Launch& l : P->launches) {
       v.push_back(l.kind); v.push_back(l.level); v.push_back(l.first);
       v.push_back(l.count); v.push_back(l.tile); v.push_back((int64_t)l.flops);
+      v.push_back(l.stream); v.push_back(l.wait0); v.push_back(l.wait1); v.push_back(l.record);
     }
     return raw(v.data(), v.size() * sizeof(int64_t));
   }

@@ -55,13 +55,20 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   ScheduleOptions so;
   so.pw = opt_.pw;
   so.tile = opt_.tile;
+  so.lookahead = opt_.lookahead;
   build_program(*S_, so, prog_);
   upload();
 }
 
 int Engine::upload() {
   const Symbolic& S = *S_;
-  HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  // the panel chain is latency-critical: give its stream the highest priority
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");
+  HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+  HIPCHK(hipStreamCreateWithPriority(&bulk_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+  dag_events_.resize(prog_.nevents);
+  for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
@@ -87,6 +94,9 @@ int Engine::upload() {
 
 Engine::~Engine() {
   if (stream_) hipStreamSynchronize(stream_);
+  if (bulk_) hipStreamSynchronize(bulk_);
+  for (auto& e : dag_events_) if (e) hipEventDestroy(e);
+  if (bulk_) hipStreamDestroy(bulk_);
   if (graph_exec_) hipGraphExecDestroy(graph_exec_);
   if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
@@ -99,12 +109,20 @@ Engine::~Engine() {
   if (stream_) hipStreamDestroy(stream_);
 }
 
-int Engine::enqueue_launch(const Launch& l) {
-  if (l.kind == L_POTRF)
-    launch_potrf(stream_, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
-  else
-    launch_update(stream_, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_,
-                  d_L_, d_relpos_, d_rlist_, d_dinv_);
+int Engine::enqueue_launch(const Launch& l, bool serial) {
+  hipStream_t st = (serial || l.stream == 0) ? stream_ : bulk_;
+  if (!serial) {
+    if (l.wait0 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait0], 0), "stream wait");
+    if (l.wait1 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait1], 0), "stream wait");
+  }
+  if (l.count > 0) {
+    if (l.kind == L_POTRF)
+      launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
+    else
+      launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
+                    d_relpos_, d_rlist_, d_dinv_);
+  }
+  if (!serial && l.record >= 0) HIPCHK(hipEventRecord(dag_events_[l.record], st), "event record");
   return 0;
 }
 
@@ -115,7 +133,12 @@ int Engine::enqueue_program() {
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
   launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, S.nnzA);
-  for (const Launch& l : prog_.launches) enqueue_launch(l);
+  for (const Launch& l : prog_.launches) {
+    int rc = enqueue_launch(l, false);
+    if (rc) return rc;
+  }
+  if (prog_.final_event >= 0)
+    HIPCHK(hipStreamWaitEvent(stream_, dag_events_[prog_.final_event], 0), "final wait");
   HIPCHK(hipGetLastError(), "kernel launch");
   HIPCHK(hipMemcpyAsync(h_flag_, d_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "flag read");
   stats_.launches = (int)prog_.launches.size() + 1;
@@ -194,7 +217,7 @@ int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<fl
   for (auto& e : ev) HIPCHK(hipEventCreate(&e), "event create");
   HIPCHK(hipEventRecord(ev[0], stream_), "event");
   for (size_t i = 0; i < nl; ++i) {
-    enqueue_launch(prog_.launches[i]);
+    enqueue_launch(prog_.launches[i], true);
     HIPCHK(hipEventRecord(ev[i + 1], stream_), "event");
   }
   HIPCHK(hipStreamSynchronize(stream_), "sync");

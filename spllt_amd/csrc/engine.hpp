@@ -19,6 +19,7 @@ struct EngineOptions {
   int pw = 64;
   int tile = 128;
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
+  bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
 };
 
 struct FactorStats {
@@ -59,7 +60,7 @@ class Engine {
  private:
   int upload();
   int enqueue_program();
-  int enqueue_launch(const Launch& l);
+  int enqueue_launch(const Launch& l, bool serial);
   int fail(int code, const char* what, hipError_t e);
 
   std::shared_ptr<const Symbolic> S_;
@@ -68,7 +69,9 @@ class Engine {
   int status_ = 0;
   std::string err_;
   int device_ = 0;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr;       // panel stream (stream 0 of the program)
+  hipStream_t bulk_ = nullptr;         // bulk stream (stream 1)
+  std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;

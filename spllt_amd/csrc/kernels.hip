@@ -38,75 +38,205 @@ __global__ __launch_bounds__(256) void k_scatter_val(double* __restrict__ L,
 }
 
 // ---------------------------------------------------------------------------
-// a11: Cholesky of one <=64 x <=64 diagonal panel block per workgroup, in LDS,
-// plus X = L^-1 (lower triangular) written to the dinv scratch (row-major,
-// ld = n, strictly-upper part zero).  A non-positive pivot records
-// (pivot column + 1) in *flag (smallest wins) and leaves the block untouched
-// from that column on.
+// a11: Cholesky of one <=64 x <=64 diagonal panel block per workgroup plus
+// X = L^-1 (lower triangular, row-major ld = n, strictly-upper part zero)
+// written to the dinv scratch.  The block lives in LDS as 4x4 sub-blocks of
+// 16x16:
+//   * off-diagonal work (block-column updates, panel solves through the
+//     inverted 16x16 diagonal blocks, and the block recurrences of the inverse)
+//     runs on v_mfma_f64_16x16x4_f64, one sub-block per wavefront;
+//   * the 16x16 diagonal blocks are factored and inverted in registers by one
+//     wavefront (lane i owns row i, columns/rows exchanged with ds_bpermute).
+// An accumulator tile S (C layout: reg r = row (l>>4)+4r, col l&15) is exactly
+// the B operand of k-step r, so X_IJ = -inv(D_I) * S needs no data movement.
+// A non-positive pivot records (pivot column + 1) in *flag (smallest wins).
 // ---------------------------------------------------------------------------
-constexpr int PLD = 65;  // LDS row stride (doubles)
+constexpr int TLD = 66;   // LDS row stride (doubles): conflict-free MFMA operand reads
+constexpr int DLD = 17;
+
+__device__ inline d4 ld_c(const double* M, int row0, int col0, int lane) {
+  const int lq = lane >> 4, lr = lane & 15;
+  d4 c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = M[(row0 + lq + 4 * r) * TLD + col0 + lr];
+  return c;
+}
+__device__ inline void st_c(double* M, int row0, int col0, int lane, d4 c) {
+  const int lq = lane >> 4, lr = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[(row0 + lq + 4 * r) * TLD + col0 + lr] = c[r];
+}
+
+// broadcast of lane `src` (compile-time constant after unrolling) through SGPRs
+__device__ inline double bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// 1/sqrt(d) and sqrt(d) to fp64 accuracy from v_rsq_f64 + Newton steps
+__device__ inline void rsqrt_sqrt(double d, double& y, double& r) {
+  y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  r = d * y;
+  r = __builtin_fma(0.5 * y, __builtin_fma(-r, r, d), r);
+}
 
 __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
                                                      double* __restrict__ L,
                                                      double* __restrict__ dinv,
                                                      int* __restrict__ flag) {
-  __shared__ double T[64 * PLD];
-  __shared__ double X[64 * PLD];
-  __shared__ int s_fail;
+  __shared__ double T[64 * TLD];
+  __shared__ double X[64 * TLD];
+  __shared__ double DI[4][16 * DLD];
+  __shared__ double RI[64];  // reciprocals of the diagonal of L
   const PotrfUnit u = units[blockIdx.x];
   const int n = u.n, ld = u.ld, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, lq = lane >> 4, lr = lane & 15;
   double* A = L + u.off;
-  if (tid == 0) s_fail = 0;
-  for (int idx = tid; idx < n * n; idx += 256) {
-    int i = idx / n, j = idx - i * n;
-    T[i * PLD + j] = (j <= i) ? A[(int64_t)i * ld + j] : 0.0;
-    X[i * PLD + j] = 0.0;
-  }
-  __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
+  const int nblk = (n + 15) >> 4;
+  const int np = nblk * 16;
   const bool do_chol = !(u.flags & 1);
-  for (int j = 0; do_chol && j < n; ++j) {
-    double d = T[j * PLD + j];
-    if (!(d > 0.0)) {  // uniform: every thread reads the same value
-      if (tid == 0) {
-        s_fail = 1;
-        atomicMin(flag, u.gcol + j + 1);
+  // identity-padded lower triangle
+  for (int idx = tid; idx < np * np; idx += 256) {
+    const int i = idx / np, j = idx - i * np;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < n && j <= i) v = A[(int64_t)i * ld + j];
+    T[i * TLD + j] = v;
+    X[i * TLD + j] = 0.0;
+    if (!do_chol && i == j) RI[i] = 1.0 / v;
+  }
+  __syncthreads();
+  for (int J = 0; do_chol && J < nblk; ++J) {
+    // A1: T[I][J] -= sum_{K<J} T[I][K] T[J][K]^T, one sub-block per wave
+    if (J > 0) {
+      const int I = J + w;
+      if (I < nblk) {
+        d4 acc = ld_c(T, I * 16, J * 16, lane);
+        for (int k = 0; k < J * 16; k += 4) {
+          const double a = -T[(I * 16 + lr) * TLD + k + lq];
+          const double b = T[(J * 16 + lr) * TLD + k + lq];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        st_c(T, I * 16, J * 16, lane, acc);
       }
-      break;
+      __syncthreads();
     }
-    d = sqrt(d);
-    const double rinv = 1.0 / d;
-    __syncthreads();
-    if (tid > j && tid < n) T[tid * PLD + j] *= rinv;
-    if (tid == j) T[j * PLD + j] = d;
-    __syncthreads();
-    for (int i = j + 1 + ty; i < n; i += 16) {
-      const double lij = T[i * PLD + j];
-      for (int k = j + 1 + tx; k <= i; k += 16) T[i * PLD + k] -= lij * T[k * PLD + j];
+    // A2: factor the diagonal 16x16 block in registers (wave 0: lane i owns
+    // row i; the four 16-lane groups hold identical copies, group 0 writes)
+    if (w == 0) {
+      double row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = T[(J * 16 + lr) * TLD + J * 16 + c];
+      int failcol = 1 << 30;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double djj = bcast(row[j], j);
+        if (!(djj > 0.0)) {
+          if (failcol == (1 << 30)) failcol = j;
+          djj = 1.0;
+        }
+        double y, d;
+        rsqrt_sqrt(djj, y, d);
+        if (lr > j) row[j] *= y;
+        else if (lr == j) row[j] = d;
+        if (lane == j) RI[J * 16 + j] = y;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) {
+          const double lkj = bcast(row[j], k);
+          if (lr >= k) row[k] -= row[j] * lkj;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[(J * 16 + lr) * TLD + J * 16 + c] = (c <= lr) ? row[c] : 0.0;
+        if (failcol != (1 << 30) && lane == 0) atomicMin(flag, u.gcol + J * 16 + failcol + 1);
+      }
     }
     __syncthreads();
+    // A3: rows of the sub-blocks below: x = a * D_J^-T by forward substitution
+    // (lane i owns row i of sub-block I; D_J and its reciprocals come from LDS)
+    {
+      const int I = J + 1 + w;
+      if (I < nblk) {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = T[(I * 16 + lr) * TLD + J * 16 + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double sacc = x[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) sacc -= x[k] * T[(J * 16 + c) * TLD + J * 16 + k];
+          x[c] = sacc * RI[J * 16 + c];
+        }
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) T[(I * 16 + lr) * TLD + J * 16 + c] = x[c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // B0: invert the diagonal 16x16 blocks, one per wave, in registers
+  if (w < nblk) {
+    double row[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      row[c] = T[(w * 16 + lr) * TLD + w * 16 + c];
+      x[c] = (c == lr) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double rk = RI[w * 16 + k];
+      if (lr == k) {
+#pragma unroll
+        for (int c = 0; c <= k; ++c) x[c] *= rk;
+      }
+#pragma unroll
+      for (int c = 0; c <= k; ++c) {
+        const double xkc = bcast(x[c], k);
+        if (lr > k) x[c] -= row[k] * xkc;
+      }
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double xv = (c <= lr) ? x[c] : 0.0;
+        DI[w][lr * DLD + c] = xv;
+        X[(w * 16 + lr) * TLD + w * 16 + c] = xv;
+      }
+    }
   }
   __syncthreads();
-  // write the factor back (lower triangle only)
-  for (int idx = tid; idx < n * n; idx += 256) {
-    int i = idx / n, j = idx - i * n;
-    if (do_chol && j <= i) A[(int64_t)i * ld + j] = T[i * PLD + j];
-  }
-  // inverse, one column per thread: X[:,c] solves L x = e_c
-  if (tid < n && !s_fail) {
-    const int c = tid;
-    X[c * PLD + c] = 1.0 / T[c * PLD + c];
-    for (int i = c + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int k = c; k < i; ++k) s += T[i * PLD + k] * X[k * PLD + c];
-      X[i * PLD + c] = -s / T[i * PLD + i];
+  // B: X_IJ = -inv(D_I) * sum_{K=J}^{I-1} L_IK X_KJ, by block diagonals
+  for (int d = 1; d < nblk; ++d) {
+    const int J = w, I = J + d;
+    if (I < nblk) {
+      d4 S = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) {
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const double a = T[(I * 16 + lr) * TLD + K * 16 + k + lq];
+          const double b = X[(K * 16 + k + lq) * TLD + J * 16 + lr];
+          S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, S, 0, 0, 0);
+        }
+      }
+      d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double a = -DI[I][lr * DLD + 4 * t + lq];
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, S[t], R, 0, 0, 0);
+      }
+      st_c(X, I * 16, J * 16, lane, R);
     }
+    __syncthreads();
   }
-  __syncthreads();
   double* D = dinv + u.dinv_off;
   for (int idx = tid; idx < n * n; idx += 256) {
-    int i = idx / n, j = idx - i * n;
-    D[idx] = X[i * PLD + j];
+    const int i = idx / n, j = idx - i * n;
+    if (do_chol && j <= i) A[(int64_t)i * ld + j] = T[i * TLD + j];
+    D[idx] = X[i * TLD + j];
   }
 }
 
@@ -121,7 +251,7 @@ constexpr int BK = 16;
 constexpr int LDK = 18;
 
 template <int T>
-__global__ __launch_bounds__(256) void k_update(const UpdTile* __restrict__ tiles,
+__global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ tiles,
                                                 const UpdUnit* __restrict__ units,
                                                 const int64_t* __restrict__ bc_off,
                                                 const int* __restrict__ bc_w,

@@ -7,6 +7,10 @@
 namespace spx {
 namespace {
 
+struct Edge {
+  int stream = 0, wait0 = -1, wait1 = -1, record = -1;
+};
+
 struct Builder {
   const Symbolic& S;
   const ScheduleOptions& opt;
@@ -39,8 +43,20 @@ struct Builder {
 
   // Emit one GEMM phase: the units in `us` are split by tile size into at most
   // two launches.
-  void emit_gemm(int level, std::vector<UpdUnit>& us, double flops, bool lower = true) {
-    if (us.empty()) return;
+  // last launch index emitted per call (to attach `record` to the final one)
+  void emit_gemm(int level, std::vector<UpdUnit>& us, double flops, bool lower = true,
+                 Edge e = Edge()) {
+    if (us.empty()) {
+      // keep the event graph consistent: an empty phase still has to forward
+      // its record event; emit a marker launch with no work
+      if (e.record >= 0 || e.wait0 >= 0 || e.wait1 >= 0) {
+        Launch L;
+        L.kind = L_GEMM; L.level = level; L.first = 0; L.count = 0; L.tile = 64; L.flops = 0;
+        L.stream = e.stream; L.wait0 = e.wait0; L.wait1 = e.wait1; L.record = e.record;
+        P.launches.push_back(L);
+      }
+      return;
+    }
     std::vector<UpdTile> t128, t64;
     for (auto& u : us) {
       int uid = (int)P.units.size();
@@ -59,6 +75,12 @@ struct Builder {
       L.count = (int64_t)tv.size();
       L.tile = pass == 0 ? 128 : 64;
       L.flops = flops * ((double)tv.size() * (pass == 0 ? 4 : 1)) / std::max(1.0, ntot);
+      L.stream = e.stream;
+      const bool first_pass = (pass == 0) || t128.empty();
+      const bool last_pass = (pass == 1) || t64.empty();
+      L.wait0 = first_pass ? e.wait0 : -1;
+      L.wait1 = first_pass ? e.wait1 : -1;
+      L.record = last_pass ? e.record : -1;
       P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
       P.launches.push_back(L);
     }
@@ -98,11 +120,16 @@ struct Builder {
     }
 
     std::vector<UpdUnit> us;
+    int ev_level = -1;  // completion event of the previous level
     for (int lev = 0; lev <= maxlevel; ++lev) {
       const auto& nodes = by_level[lev];
       if (nodes.empty()) continue;
       int maxnc = 0;
       for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
+      const bool la = opt.lookahead;
+      bool first_of_level = true;   // first panel-stream launch waits for the previous level
+      int evB_prev = -1;            // bulk event of step c-1 (trailing update of c-1 -> c+1..)
+      int evP_last = -1;            // panel event of the last finished step
       for (int c = 0; c < maxnc; ++c) {
         int maxp = 0;
         for (int s : nodes) {
@@ -175,6 +202,10 @@ struct Builder {
             L.count = (int64_t)P.potrf_units.size() - L.first;
             L.flops = fl;
             P.flops_potrf += fl;
+            if (la && first_of_level) {
+              L.wait0 = ev_level;  // everything of the previous level (incl. its bulk stream)
+              first_of_level = false;
+            }
             if (L.count > 0) P.launches.push_back(L);
           }
           // (3) TRSM of the rows below the panel: X = A * inv(Lpp)^T (in place)
@@ -218,8 +249,18 @@ struct Builder {
           P.flops_trsm += fl;
           emit_gemm(lev, us, fl, false);
         }
-        // (4) right-looking update of the node's later block columns, K = blkn
-        double fl = 0;
+        // (4) right-looking update of the node's later block columns, K = blkn.
+        // With lookahead the update of block column c+1 stays on the panel
+        // stream (it gates the next panel chain) and the rest goes to the bulk
+        // stream, where it overlaps the panel chain of block column c+1.
+        int evP = -1;
+        if (la) {
+          evP = P.nevents++;
+          P.launches.back().record = evP;  // last launch of the panel chain of step c
+          evP_last = evP;
+        }
+        std::vector<UpdUnit> us_bulk;
+        double fl = 0, fl_bulk = 0;
         for (int s : nodes) {
           int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
           if (c + 1 >= nc) continue;
@@ -245,12 +286,30 @@ struct Builder {
             u.N = D.width;
             u.k0 = 0;
             u.klen = B.width;
-            us.push_back(u);
-            fl += 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+            const double f1 = 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+            if (la && jj > c + 1) { us_bulk.push_back(u); fl_bulk += f1; }
+            else { us.push_back(u); fl += f1; }
           }
         }
-        P.flops_update += fl;
-        emit_gemm(lev, us, fl);
+        P.flops_update += fl + fl_bulk;
+        if (!la) {
+          emit_gemm(lev, us, fl);
+        } else {
+          Edge e0;  // c -> c+1 on the panel stream, after the bulk update (c-1 -> c+1..)
+          e0.stream = 0;
+          e0.wait0 = evB_prev;
+          if (!us.empty()) emit_gemm(lev, us, fl, true, e0);
+          int evB = -1;
+          if (!us_bulk.empty()) {
+            Edge e1;
+            e1.stream = 1;
+            e1.wait0 = evP;
+            evB = P.nevents++;
+            e1.record = evB;
+            emit_gemm(lev, us_bulk, fl_bulk, true, e1);
+          }
+          evB_prev = evB;
+        }
       }
       // (5) inter-node updates of the whole level (update_between + scatter)
       double fl = 0;
@@ -315,8 +374,20 @@ struct Builder {
         }
       }
       P.flops_between += fl;
-      emit_gemm(lev, us, fl);
+      if (!la) {
+        emit_gemm(lev, us, fl);
+      } else {
+        // bulk stream, after the last panel chain of the level; its completion
+        // event gates the first panel launch of the next level
+        Edge e;
+        e.stream = 1;
+        e.wait0 = evP_last;
+        ev_level = P.nevents++;
+        e.record = ev_level;
+        emit_gemm(lev, us, fl, true, e);
+      }
     }
+    P.final_event = ev_level;
   }
 };
 

@@ -75,6 +75,12 @@ struct Launch {
   int64_t first, count;  // range in potrf_units (L_POTRF) or tiles (L_GEMM)
   int tile;              // L_GEMM: tile edge (128 or 64 ...)
   double flops;          // useful flops of this launch (for reporting)
+  // stream-DAG edges: the launch goes to `stream` (0 = panel stream: POTRF/TRSM
+  // chain, 1 = bulk stream: trailing and inter-node updates) after waiting for
+  // events wait0/wait1 (-1 = none) and records event `record` (-1 = none).
+  int stream = 0;
+  int wait0 = -1, wait1 = -1;
+  int record = -1;
 };
 
 struct Program {
@@ -85,6 +91,8 @@ struct Program {
   std::vector<Launch> launches;
   std::vector<int> relpos;      // per (node, touched ancestor): positions of the node's rows in the ancestor's row list
   int64_t dinv_size = 0;        // doubles
+  int nevents = 0;              // number of distinct event ids used by the launches
+  int final_event = -1;         // recorded (on the bulk stream) when everything is done
   double flops_potrf = 0, flops_trsm = 0, flops_update = 0, flops_between = 0;
 };
 
@@ -96,6 +104,8 @@ struct ScheduleOptions {
   const int* node_owner = nullptr;  // nnodes: owning rank, or -1 = replicated (top tree)
   int phase = 0;        // 0 = everything owned/replicated in one program;
                         // 1 = only nodes owned by `rank`; 2 = only replicated nodes
+  bool lookahead = true;  // two-stream schedule: panel chain of block column c+1
+                          // overlaps the trailing update by block column c
 };
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);

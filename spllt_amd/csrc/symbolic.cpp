@@ -386,6 +386,19 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
   }
   S.maxdepth = 0;
   for (int s = 0; s < nn; ++s) S.maxdepth = std::max(S.maxdepth, S.level[s] + 1);
+  // Schedule levels are ALAP: a node sits one level below its parent (roots on
+  // the top level), so that siblings -- subtrees of similar size in a nested
+  // dissection tree -- share batched launches.  Children always have a strictly
+  // smaller level than their parent.
+  for (int s = nn - 1; s >= 0; --s) {
+    int p = S.sparent[s];
+    S.level[s] = (p < nn) ? S.level[p] - 1 : S.maxdepth - 1;
+  }
+  {
+    int mn = 0;
+    for (int s = 0; s < nn; ++s) mn = std::min(mn, S.level[s]);
+    for (int s = 0; s < nn; ++s) S.level[s] -= mn;
+  }
 
   // ---- row lists (supernodal symbolic factorisation) -------------------
   S.rptr.assign(nn + 1, 0);

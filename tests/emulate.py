@@ -41,7 +41,7 @@ def emulate_program(f, val):
             out[i] = arena[s:s + klen]
         return out
 
-    for kind, level, first, count, tile, _ in launches:
+    for kind, level, first, count, tile, _fl, _st, _w0, _w1, _rec in launches:
         if kind == 0:
             for q in potrf[first:first + count]:
                 n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])

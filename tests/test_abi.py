@@ -1,0 +1,83 @@
+"""CPU test of the drop-in boundary: libspllt_hip.so loads without a GPU,
+exports every symbol include/*.h declares, and the non-GPU entry points
+(analyse, workspace sizing, task-manager tokens, chkerr, deallocate) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from spllt_amd import _lib, api, matgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(spllt_\w+)\s*\(", txt)) - {"SPLLT_OPTIONS_NULL"}
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib.load()
+    names = _declared("spllt_iface.h") | _declared("spllt_hip.h")
+    assert set(_lib.IFACE_SYMBOLS) <= names and set(_lib.HIP_SYMBOLS) <= names
+    missing = [s for s in sorted(names) if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_reference_abi():
+    assert C.sizeof(api.spllt_options_t) == 14 * 4     # include/spllt_iface.h:14-31
+    assert C.sizeof(api.spllt_inform_t) == 6 * 4       # :49-57
+    o = api.spllt_options_t.default()
+    assert (o.nb, o.nemin, o.prune_tree, o.ncpu, o.min_width_blas) == (16, 32, 1, 1, 8)
+
+
+def test_analyse_without_gpu_and_factor_fails_loudly():
+    A = matgen.poisson2d(10)
+    n, ptr, row, val = api.csc_lower_1based(A)
+    f = api.Factorization(n, ptr, row, nb=8)
+    assert f.info.flag == 0 and f.info.num_nodes == f.sym_info()["nnodes"]
+    assert sorted(f.order[:n].tolist()) == list(range(1, n + 1))   # 1-based positions
+    ws = C.c_long()
+    f.lib.spllt_solve_workspace_size(f.fkeep, 2, 3, C.byref(ws))
+    assert ws.value == n * 3 + (f.sym_info()["maxmn"] + n) * 3 * 2  # src/spllt_data_mod.F90:655
+    import torch
+    if not torch.cuda.is_available():
+        try:
+            f.factor(val)
+            raised = False
+        except api.SplltError as e:
+            raised = e.flag == -30
+        assert raised, "spllt_factor must fail loudly without a HIP device (no CPU fallback)"
+    f.close()
+    assert f.akeep.value is None and f.fkeep.value is None
+
+
+def test_bad_arguments_set_flag_not_abort():
+    lib = _lib.load()
+    info = api.spllt_inform_t()
+    lib.spllt_factor(None, None, None, 0, None, C.byref(info))
+    assert info.flag == -10
+    x = np.zeros(3)
+    lib.spllt_solve(None, None, None, 1, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info), 0)
+    assert info.flag == -10
+    tm = C.c_void_p(None)
+    lib.spllt_task_manager_init(C.byref(tm))
+    assert tm.value is not None
+    st = C.c_int(7)
+    lib.spllt_task_manager_deallocate(C.byref(tm), C.byref(st))
+    assert tm.value is None and st.value == 0
+    lib.spllt_wait()  # nothing pending: returns
+
+
+def test_unknown_solve_job_is_rejected_like_reference():
+    """src/spllt_solve_mod.F90:216-220: job outside 0..2 -> SPLLT_WARNING_PARAM_VALUE (-10);
+    example/C/simple.c:69 passes 6 and gets exactly this."""
+    A = matgen.poisson2d(6)
+    n, ptr, row, val = api.csc_lower_1based(A)
+    f = api.Factorization(n, ptr, row, nb=8)
+    x = np.ones(n)
+    f.lib.spllt_solve(f.fkeep, C.byref(f.options), f.order.ctypes.data_as(C.POINTER(C.c_int)), 1,
+                      x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(f.info), 6)
+    assert f.info.flag == -10

@@ -114,3 +114,87 @@ def sparent_of(f, a, _cache={}):
     if key not in _cache:
         _cache[key] = f.sym("sparent")
     return int(_cache[key][a])
+
+
+def _access_sets(f):
+    """Per launch: (reads, writes, atomics) as sets of block-column ids, plus
+    dinv slots (offset by nbcol) -- the granularity at which the stream DAG
+    must order conflicting launches."""
+    launches = f.program("launches")
+    potrf, units, tiles = f.program("potrf"), f.program("units"), f.program("tiles")
+    off = f.sym("bcol_off")
+    nbc = len(off)
+    out = []
+    for kind, level, first, count, tile, _fl, st, w0, w1, rec in launches:
+        R, W, At = set(), set(), set()
+        if kind == 0:
+            for q in potrf[first:first + count]:
+                b = int(np.searchsorted(off, q["off"], side="right") - 1)
+                W.add(b)
+                R.add(b)
+                W.add(nbc + int(q["dinv_off"]))
+        else:
+            for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
+                u = units[uid]
+                db = int(np.searchsorted(off, u["d_off"], side="right") - 1)
+                for sg in range(int(u["nseg"])):
+                    R.add(int(u["src_bcol0"]) + sg)
+                if u["mode"] == 2:
+                    R.add(nbc + int(u["dinv_off"]))
+                    W.add(db)
+                elif u["mode"] == 1:
+                    At.add(db)
+                else:
+                    W.add(db)
+        out.append((R, W, At))
+    return launches, out
+
+
+@pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
+                                        (lambda: matgen.poisson2d(40), 16, 16),
+                                        (lambda: matgen.poisson3d(9), 24, 8)])
+def test_stream_dag_orders_every_conflict(gen, nb, pw):
+    """Two-stream lookahead program: any two launches that touch the same block
+    column (write/write, read/write, atomic/plain) must be ordered by stream
+    order or an event edge; concurrent atomics into one destination are fine."""
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=8, panel_width=pw)
+    launches, acc = _access_sets(f)
+    n = len(launches)
+    assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
+    rec_at = {}
+    last_in_stream = {}
+    before = [0] * n  # bitset of launches that happen-before launch i
+    for i, (kind, level, first, count, tile, _fl, st, w0, w1, rec) in enumerate(launches):
+        m = 0
+        if st in last_in_stream:
+            j = last_in_stream[st]
+            m |= before[j] | (1 << j)
+        for w in (w0, w1):
+            if w >= 0:
+                j = rec_at[w]          # a wait must refer to an earlier record
+                m |= before[j] | (1 << j)
+        before[i] = m
+        last_in_stream[st] = i
+        if rec >= 0:
+            rec_at[int(rec)] = i
+    for j in range(n):
+        Rj, Wj, Aj = acc[j]
+        for i in range(j):
+            Ri, Wi, Ai = acc[i]
+            conflict = (Wi & (Rj | Wj | Aj)) or (Wj & (Ri | Ai)) or (Ai & Rj) or (Aj & Ri)
+            if conflict:
+                assert before[j] >> i & 1, (i, j, launches[i].tolist(), launches[j].tolist())
+    # the final event covers everything: last launch of each stream precedes it
+    fin = max(rec_at.values())
+    for st, i in last_in_stream.items():
+        assert i == fin or (before[fin] >> i & 1) or st == launches[fin, 6]
+
+
+def test_single_stream_program_has_no_events():
+    A = matgen.poisson2d(20)
+    f, val = make_case(A, nb=8, nemin=4, engine_flags=2)
+    L = f.program("launches")
+    assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all()
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
