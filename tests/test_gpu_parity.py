@@ -254,3 +254,17 @@ def test_scatter_block_twin():
                                                    t[4].data_ptr(), d_n, t[5].data_ptr(), d_n) == 0
     torch.cuda.synchronize()
     assert np.array_equal(t[5].cpu().numpy(), exp)  # integer index work + one subtract: bit-exact
+
+
+def test_fortran_api_kat():
+    """example/C/simple.c's case through the Fortran API module
+    (spllt_amd/fortran/spllt_hip_mod.F90, built by __graft_entry__.build() with flang)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spllt_amd",
+                       "fortran", "kat_simple")
+    if not os.path.exists(exe):
+        pytest.skip("flang was not available at build time")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1.50000000  2.00000000  1.50000000" in r.stdout
