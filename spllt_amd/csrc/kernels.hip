@@ -83,6 +83,13 @@ __device__ inline void rsqrt_sqrt(double d, double& y, double& r) {
   r = __builtin_fma(0.5 * y, __builtin_fma(-r, r, d), r);
 }
 
+#ifdef POTRF_STAMPS
+__device__ unsigned long long g_potrf_stamps[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
                                                      double* __restrict__ L,
                                                      double* __restrict__ dinv,
@@ -98,16 +105,27 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
   const int nblk = (n + 15) >> 4;
   const int np = nblk * 16;
   const bool do_chol = !(u.flags & 1);
-  // identity-padded lower triangle
-  for (int idx = tid; idx < np * np; idx += 256) {
-    const int i = idx / np, j = idx - i * np;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < n && j <= i) v = A[(int64_t)i * ld + j];
-    T[i * TLD + j] = v;
-    X[i * TLD + j] = 0.0;
-    if (!do_chol && i == j) RI[i] = 1.0 / v;
+  STAMP(0);
+  // identity-padded lower triangle: thread t owns 16 consecutive columns of row t/4
+  const int li = tid >> 2, lj0 = (tid & 3) * 16;
+  {
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = lj0 + e;
+      v[e] = (li < n && j <= li) ? A[(int64_t)li * ld + j] : ((li == j) ? 1.0 : 0.0);
+    }
+    if (li < np) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        T[li * TLD + lj0 + e] = v[e];
+        X[li * TLD + lj0 + e] = 0.0;
+        if (!do_chol && lj0 + e == li) RI[li] = 1.0 / v[e];
+      }
+    }
   }
   __syncthreads();
+  STAMP(1);
   for (int J = 0; do_chol && J < nblk; ++J) {
     // A1: T[I][J] -= sum_{K<J} T[I][K] T[J][K]^T, one sub-block per wave
     if (J > 0) {
@@ -123,6 +141,7 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
       }
       __syncthreads();
     }
+    STAMP(2 + 3 * J);
     // A2: factor the diagonal 16x16 block in registers (wave 0: lane i owns
     // row i; the four 16-lane groups hold identical copies, group 0 writes)
     if (w == 0) {
@@ -132,6 +151,11 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
       int failcol = 1 << 30;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
+        // unscaled column j of the other rows: independent of the pivot's
+        // reciprocal square root, so the readlanes overlap its latency
+        double tk[16];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) tk[k] = bcast(row[j], k);
         double djj = bcast(row[j], j);
         if (!(djj > 0.0)) {
           if (failcol == (1 << 30)) failcol = j;
@@ -139,14 +163,13 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
         }
         double y, d;
         rsqrt_sqrt(djj, y, d);
-        if (lr > j) row[j] *= y;
-        else if (lr == j) row[j] = d;
-        if (lane == j) RI[J * 16 + j] = y;
+        const double sc = row[j] * (y * y);   // L_ij * y  (= row[j] * y^2)
+        // unconditional: entries above the diagonal (lr < k) become garbage
+        // that nothing reads (the write-back masks them)
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-          const double lkj = bcast(row[j], k);
-          if (lr >= k) row[k] -= row[j] * lkj;
-        }
+        for (int k = j + 1; k < 16; ++k) row[k] -= sc * tk[k];
+        row[j] = (lr == j) ? d : row[j] * y;
+        RI[J * 16 + j] = y;  // wave-uniform value, every lane stores the same word
       }
       if (lane < 16) {
 #pragma unroll
@@ -155,6 +178,7 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
       }
     }
     __syncthreads();
+    STAMP(3 + 3 * J);
     // A3: rows of the sub-blocks below: x = a * D_J^-T by forward substitution
     // (lane i owns row i of sub-block I; D_J and its reciprocals come from LDS)
     {
@@ -177,38 +201,30 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
       }
     }
     __syncthreads();
+    STAMP(4 + 3 * J);
   }
-  // B0: invert the diagonal 16x16 blocks, one per wave, in registers
+  // B0: invert the diagonal 16x16 blocks, one per wave: lane c owns COLUMN c of
+  // inv(D_w) and solves D_w x = e_c by forward substitution; the entries of D_w
+  // are wave-uniform LDS reads, so no cross-lane traffic is needed
   if (w < nblk) {
-    double row[16], x[16];
+    double x[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      row[c] = T[(w * 16 + lr) * TLD + w * 16 + c];
-      x[c] = (c == lr) ? 1.0 : 0.0;
-    }
+    for (int i = 0; i < 16; ++i) {
+      double sacc = (i == lr) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const double rk = RI[w * 16 + k];
-      if (lr == k) {
-#pragma unroll
-        for (int c = 0; c <= k; ++c) x[c] *= rk;
-      }
-#pragma unroll
-      for (int c = 0; c <= k; ++c) {
-        const double xkc = bcast(x[c], k);
-        if (lr > k) x[c] -= row[k] * xkc;
-      }
+      for (int k = 0; k < i; ++k) sacc -= T[(w * 16 + i) * TLD + w * 16 + k] * x[k];
+      x[i] = (i >= lr) ? sacc * RI[w * 16 + i] : 0.0;
     }
     if (lane < 16) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double xv = (c <= lr) ? x[c] : 0.0;
-        DI[w][lr * DLD + c] = xv;
-        X[(w * 16 + lr) * TLD + w * 16 + c] = xv;
+      for (int i = 0; i < 16; ++i) {
+        DI[w][i * DLD + lr] = x[i];
+        X[(w * 16 + i) * TLD + w * 16 + lr] = x[i];
       }
     }
   }
   __syncthreads();
+  STAMP(14);
   // B: X_IJ = -inv(D_I) * sum_{K=J}^{I-1} L_IK X_KJ, by block diagonals
   for (int d = 1; d < nblk; ++d) {
     const int J = w, I = J + d;
@@ -232,12 +248,19 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
     }
     __syncthreads();
   }
+  STAMP(15);
   double* D = dinv + u.dinv_off;
-  for (int idx = tid; idx < n * n; idx += 256) {
-    const int i = idx / n, j = idx - i * n;
-    if (do_chol && j <= i) A[(int64_t)i * ld + j] = T[i * TLD + j];
-    D[idx] = X[i * TLD + j];
+  if (li < n) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = lj0 + e;
+      if (j < n) {
+        if (do_chol && j <= li) A[(int64_t)li * ld + j] = T[li * TLD + j];
+        D[li * n + j] = X[li * TLD + j];
+      }
+    }
   }
+  STAMP(16);
 }
 
 // ---------------------------------------------------------------------------
@@ -276,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
   const int skof = (tid % TPR) * PER;    // first k of its chunk
   const bool rowA_ok = (i0 + srow) < M;
   const bool rowB_ok = (j0 + srow) < N;
+  const int rowA = rowA_ok ? i0 + srow : M - 1;   // clamped: always a valid row
+  const int rowB = rowB_ok ? j0 + srow : N - 1;
 
   d4 acc[FM][FM];
 #pragma unroll
@@ -296,35 +321,48 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
     const int kbeg = (u.nseg == 1) ? u.k0 : 0;
     klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;
     lda = w;
-    aptr = L + base + (int64_t)(u.src_r0 + i0 + srow - rshift) * w + kbeg + skof;
+    aptr = L + base + (int64_t)(u.src_r0 + rowA - rshift) * w + kbeg + skof;
     if (u.mode == MODE_TRSM) {
       ldb = u.dinv_ld;
-      bptr = dinv + u.dinv_off + (int64_t)(j0 + srow) * ldb + skof;
+      bptr = dinv + u.dinv_off + (int64_t)rowB * ldb + skof;
     } else if (u.b_bcol0 >= 0) {
       const int bb = u.b_bcol0 + sg;
       ldb = bc_w[bb];
       bptr = L + bc_off[bb] +
-             (int64_t)(u.src_c0 + j0 + srow - (u.b_seg_r0 + sg * u.seg_stride)) * ldb + kbeg + skof;
+             (int64_t)(u.src_c0 + rowB - (u.b_seg_r0 + sg * u.seg_stride)) * ldb + kbeg + skof;
     } else {
       ldb = w;
-      bptr = L + base + (int64_t)(u.src_c0 + j0 + srow - rshift) * w + kbeg + skof;
+      bptr = L + base + (int64_t)(u.src_c0 + rowB - rshift) * w + kbeg + skof;
     }
   };
   double ra[PER], rb[PER];
+  // Loads are unconditional (no per-element branches): rows beyond the tile
+  // edge re-read the last valid row and K beyond the window re-reads its last
+  // column; the values are zeroed afterwards.
   auto load_regs = [&]() {
     const int kleft = klen - (kk + skof);  // valid elements in this thread's chunk
     if (kleft >= PER) {
 #pragma unroll
       for (int e = 0; e < PER; ++e) {
-        ra[e] = rowA_ok ? aptr[kk + e] : 0.0;
-        rb[e] = rowB_ok ? bptr[kk + e] : 0.0;
+        ra[e] = aptr[kk + e];
+        rb[e] = bptr[kk + e];
       }
     } else {
 #pragma unroll
       for (int e = 0; e < PER; ++e) {
-        ra[e] = (rowA_ok && e < kleft) ? aptr[kk + e] : 0.0;
-        rb[e] = (rowB_ok && e < kleft) ? bptr[kk + e] : 0.0;
+        const int ke = kk + (e < kleft ? e : (kleft > 0 ? kleft - 1 : -skof));
+        ra[e] = aptr[ke];
+        rb[e] = bptr[ke];
+        if (e >= kleft) { ra[e] = 0.0; rb[e] = 0.0; }
       }
+    }
+    if (!rowA_ok) {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) ra[e] = 0.0;
+    }
+    if (!rowB_ok) {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) rb[e] = 0.0;
     }
   };
 

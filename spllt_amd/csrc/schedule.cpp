@@ -27,10 +27,12 @@ struct Builder {
     return (M >= 96 && N >= 96) ? 128 : 64;
   }
 
-  // Append the tiles of unit `u` (edge T); returns useful flops.
-  void add_tiles(std::vector<UpdTile>& out, int uid, const UpdUnit& u, int T, bool lower) {
-    int nti = cdiv(u.M, T), ntj = cdiv(u.N, T);
-    for (int tj = 0; tj < ntj; ++tj)
+  // Append the tiles of unit `u` covering columns [jbeg, jend) with tiles of
+  // edge T (tile indices are in units of T; jbeg is a multiple of T).
+  void add_tiles(std::vector<UpdTile>& out, int uid, const UpdUnit& u, int T, bool lower,
+                 int jbeg, int jend) {
+    int nti = cdiv(u.M, T);
+    for (int tj = jbeg / T; tj * T < jend; ++tj)
       for (int ti = 0; ti < nti; ++ti) {
         if (lower && u.src_r0 + (ti + 1) * T - 1 < u.src_c0 + tj * T) continue;
         UpdTile t;
@@ -62,7 +64,18 @@ struct Builder {
       int uid = (int)P.units.size();
       P.units.push_back(u);
       int T = (u.mode == MODE_TRSM) ? (u.N > 64 ? 128 : pick_tile(u.M, u.N)) : pick_tile(u.M, u.N);
-      add_tiles(T == 128 ? t128 : t64, uid, u, T, lower && u.lower);
+      const bool low = lower && u.lower;
+      if (T == 128 && u.mode != MODE_TRSM) {
+        // 128-wide tile columns, except a trailing remainder of <= 64 columns
+        // which is covered by 64-wide tiles (a mostly empty 128-column would
+        // waste up to half of its MFMAs)
+        int rem = u.N % 128;
+        int full = (rem > 0 && rem <= 64) ? u.N - rem : u.N;
+        if (full > 0) add_tiles(t128, uid, u, 128, low, 0, full);
+        if (full < u.N) add_tiles(t64, uid, u, 64, low, full, u.N);
+      } else {
+        add_tiles(T == 128 ? t128 : t64, uid, u, T, low, 0, u.N);
+      }
     }
     double ntot = (double)t128.size() * 4 + (double)t64.size();
     for (int pass = 0; pass < 2; ++pass) {
