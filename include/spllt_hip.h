@@ -96,6 +96,22 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * replay through a hipGraph, bit 1 = single-stream program (no lookahead) */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 
+/* ---- multi-GPU: one process per GPU, subtree partition ----------------------
+ * Call after spllt_analyse (options.prune_tree = 1, options.ncpu = nranks) and
+ * before the first spllt_factor.  Every rank factorizes the pruned subtrees it
+ * owns; spllt_factor then stops at the exchange point with the top-tree block
+ * columns packed into the caller's device buffer (exchange_elems doubles).
+ * The caller sums that buffer over all ranks (RCCL all-reduce over xGMI: this
+ * is the extend-add that replaces spllt_scatter_block on generated elements,
+ * reference src/spllt_factorization_mod.F90:39-191), calls spllt_hip_continue,
+ * then spllt_wait/spllt_hip_wait.  The top tree is factorized on every rank. */
+int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange_elems);
+int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
+int spllt_hip_continue(void *fkeep);
+/* "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),
+ * "map_keep" (uint8 per val->L map entry: scattered on this rank) */
+int64_t spllt_hip_partition_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
+
 /* spllt_factor with val already resident in HBM (device pointer) */
 void spllt_hip_factor_dev(void *akeep, void *fkeep, spllt_options_t *options, int nnz,
                           const double *val_dev, spllt_inform_t *info);

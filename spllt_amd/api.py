@@ -189,6 +189,36 @@ class Factorization:
             raise SplltError("spllt_solve", self.info.flag, self.last_error())
         return x
 
+    # ---- multi-GPU subtree partition ------------------------------------------
+    def set_partition(self, rank, nranks):
+        """Declare this process as `rank` of `nranks`; returns the number of
+        doubles of the top-tree exchange buffer (0 for nranks == 1)."""
+        n = C.c_int64()
+        rc = self.lib.spllt_hip_set_partition(self.fkeep, rank, nranks, C.byref(n))
+        if rc < 0:
+            raise SplltError("spllt_hip_set_partition", rc)
+        return n.value
+
+    def set_exchange_buffer(self, dev_ptr):
+        rc = self.lib.spllt_hip_set_exchange_buffer(self.fkeep, C.c_void_p(dev_ptr))
+        if rc < 0:
+            raise SplltError("spllt_hip_set_exchange_buffer", rc)
+
+    def continue_after_exchange(self):
+        rc = self.lib.spllt_hip_continue(self.fkeep)
+        if rc < 0:
+            raise SplltError("spllt_hip_continue", rc, self.last_error())
+        return self
+
+    def partition(self, name):
+        nbytes = self.lib.spllt_hip_partition_get(self.fkeep, name.encode(), None, 0)
+        if nbytes < 0:
+            raise KeyError(name)
+        raw = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        self.lib.spllt_hip_partition_get(self.fkeep, name.encode(), raw.ctypes.data, nbytes)
+        raw = raw[:nbytes]
+        return raw if name == "map_keep" else raw.view(np.int32)
+
     def profile(self, val):
         val = np.ascontiguousarray(val, dtype=np.float64)
         nl = len(self.program("launches"))

@@ -38,6 +38,7 @@ struct Fkeep {
   double* y = nullptr;
   double* workspace = nullptr;
   long worksize = 0;
+  double* xbuf = nullptr;  // multi-GPU exchange buffer (caller-owned device memory)
 };
 
 std::mutex g_mu;
@@ -158,6 +159,7 @@ void factor_impl(void* akeep, void* fkeep, int nnz, const double* val, bool dev,
   if (!f->eng) {
     f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
     if (!f->eng) { if (info) info->flag = SPLLT_ERROR_ALLOCATION; return; }
+    f->eng->set_exchange_buffer(f->xbuf);
   }
   if (f->eng->status()) {
     f->last_flag = f->eng->status();
@@ -453,6 +455,80 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) 
   return 0;
 }
 
+// ---- multi-GPU partition ---------------------------------------------------
+// Works without a GPU (tests inspect the partition and the two-phase program):
+// the owners are recomputed from the symbolic structure when no engine exists.
+static void partition_tables(Fkeep* f, std::vector<int>& owner, std::vector<int>& top,
+                             std::vector<char>& keep, int64_t& elems) {
+  const Symbolic& S = *f->S;
+  assign_owners(S, f->eo.nranks, owner);
+  top.clear();
+  elems = 0;
+  for (int b = 0; b < S.nbcol(); ++b)
+    if (owner[S.bcols[b].node] < 0) {
+      top.push_back(b);
+      elems += (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+    }
+  keep.assign(S.map_dst.size(), 0);
+  for (int b = 0; b < S.nbcol(); ++b) {
+    const int own = owner[S.bcols[b].node];
+    if ((own == f->eo.rank) || (own < 0 && f->eo.rank == 0))
+      for (int64_t i = S.lmap_ptr[b]; i < S.lmap_ptr[b + 1]; ++i) keep[i] = 1;
+  }
+}
+
+int spllt_hip_set_partition(void* fkeep, int rank, int nranks, int64_t* exchange_elems) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || nranks < 1 || rank < 0 || rank >= nranks) return SPLLT_ERROR_PARAMETER;
+  if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
+  f->eo.rank = rank;
+  f->eo.nranks = nranks;
+  std::vector<int> owner, top;
+  std::vector<char> keep;
+  int64_t elems = 0;
+  partition_tables(f, owner, top, keep, elems);
+  if (exchange_elems) *exchange_elems = nranks > 1 ? elems : 0;
+  return 0;
+}
+
+int spllt_hip_set_exchange_buffer(void* fkeep, void* dev_ptr) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S) return SPLLT_ERROR_PARAMETER;
+  f->xbuf = static_cast<double*>(dev_ptr);
+  if (f->eng) f->eng->set_exchange_buffer(f->xbuf);
+  return 0;
+}
+
+int spllt_hip_continue(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->eng) return SPLLT_ERROR_PARAMETER;
+  int rc = f->eng->continue_after_exchange();
+  f->last_flag = rc;
+  if (rc == 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (std::find(g_pending.begin(), g_pending.end(), f) == g_pending.end()) g_pending.push_back(f);
+  }
+  return rc;
+}
+
+int64_t spllt_hip_partition_get(void* fkeep, const char* name, void* buf, int64_t cap) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !name) return -1;
+  std::vector<int> owner, top;
+  std::vector<char> keep;
+  int64_t elems = 0;
+  partition_tables(f, owner, top, keep, elems);
+  std::string k(name);
+  auto raw = [&](const void* p, size_t bytes) -> int64_t {
+    if (buf && bytes) std::memcpy(buf, p, std::min<size_t>(bytes, (size_t)cap));
+    return (int64_t)bytes;
+  };
+  if (k == "owner") return raw(owner.data(), owner.size() * sizeof(int));
+  if (k == "top_bcols") return raw(top.data(), top.size() * sizeof(int));
+  if (k == "map_keep") return raw(keep.data(), keep.size());
+  return -1;
+}
+
 int spllt_hip_get_factor(void* fkeep, double* out, int64_t count) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f || !out) return SPLLT_ERROR_PARAMETER;
@@ -491,6 +567,13 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.pw = f->eo.pw;
     so.tile = f->eo.tile;
     so.lookahead = f->eo.lookahead;
+    std::vector<int> owner;
+    if (f->eo.nranks > 1) {
+      assign_owners(*f->S, f->eo.nranks, owner);
+      so.node_owner = owner.data();
+      so.rank = f->eo.rank;
+      so.nranks = f->eo.nranks;
+    }
     build_program(*f->S, so, local);
     P = &local;
   }

@@ -56,7 +56,20 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.pw = opt_.pw;
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
+  if (opt_.nranks > 1) {
+    assign_owners(*S_, opt_.nranks, owner_);
+    so.node_owner = owner_.data();
+    so.rank = opt_.rank;
+    so.nranks = opt_.nranks;
+    for (int b = 0; b < S_->nbcol(); ++b)
+      if (owner_[S_->bcols[b].node] < 0) {
+        top_bcols_.push_back(b);
+        xchg_elems_ += (int64_t)S_->bcols[b].nrow * S_->bcols[b].width;
+      }
+  }
   build_program(*S_, so, prog_);
+  for (size_t i = 0; i < prog_.launches.size(); ++i)
+    if (prog_.launches[i].kind == L_EXCHANGE) xchg_idx_ = (int)i;
   upload();
 }
 
@@ -75,8 +88,29 @@ int Engine::upload() {
   HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "hipMalloc(L arena)");
   HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
   HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)std::max<int64_t>(1, prog_.dinv_size)), "hipMalloc(dinv)");
-  HIPCHK(dev_upload(&d_map_dst_, S.map_dst), "upload map_dst");
-  HIPCHK(dev_upload(&d_map_src_, S.map_src), "upload map_src");
+  if (opt_.nranks > 1) {
+    // this rank scatters A only into its own subtrees; the top tree's values
+    // are contributed by rank 0 alone so that the cross-rank sum holds them once
+    std::vector<int64_t> md, ms;
+    map_keep_.assign(S.map_dst.size(), 0);
+    for (int b = 0; b < S.nbcol(); ++b) {
+      const int own = owner_[S.bcols[b].node];
+      const bool keep = (own == opt_.rank) || (own < 0 && opt_.rank == 0);
+      if (!keep) continue;
+      for (int64_t i = S.lmap_ptr[b]; i < S.lmap_ptr[b + 1]; ++i) {
+        map_keep_[i] = 1;
+        md.push_back(S.map_dst[i]);
+        ms.push_back(S.map_src[i]);
+      }
+    }
+    nmap_ = (int64_t)md.size();
+    HIPCHK(dev_upload(&d_map_dst_, md), "upload map_dst");
+    HIPCHK(dev_upload(&d_map_src_, ms), "upload map_src");
+  } else {
+    nmap_ = S.nnzA;
+    HIPCHK(dev_upload(&d_map_dst_, S.map_dst), "upload map_dst");
+    HIPCHK(dev_upload(&d_map_src_, S.map_src), "upload map_src");
+  }
   std::vector<int64_t> off(S.nbcol());
   std::vector<int> w(S.nbcol());
   for (int b = 0; b < S.nbcol(); ++b) { off[b] = S.bcols[b].off; w[b] = S.bcols[b].width; }
@@ -115,7 +149,7 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
     if (l.wait0 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait0], 0), "stream wait");
     if (l.wait1 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait1], 0), "stream wait");
   }
-  if (l.count > 0) {
+  if (l.count > 0 && l.kind != L_EXCHANGE) {
     if (l.kind == L_POTRF)
       launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     else
@@ -126,22 +160,80 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
   return 0;
 }
 
+int Engine::enqueue_range(size_t first, size_t last) {
+  for (size_t i = first; i < last; ++i) {
+    int rc = enqueue_launch(prog_.launches[i], false);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int Engine::finish_enqueue() {
+  if (prog_.final_event >= 0)
+    HIPCHK(hipStreamWaitEvent(stream_, dag_events_[prog_.final_event], 0), "final wait");
+  HIPCHK(hipGetLastError(), "kernel launch");
+  HIPCHK(hipMemcpyAsync(h_flag_, d_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "flag read");
+  return 0;
+}
+
 int Engine::enqueue_program() {
   const Symbolic& S = *S_;
   HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
   const int big = INT_MAX;
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
-  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, S.nnzA);
-  for (const Launch& l : prog_.launches) {
-    int rc = enqueue_launch(l, false);
-    if (rc) return rc;
-  }
-  if (prog_.final_event >= 0)
-    HIPCHK(hipStreamWaitEvent(stream_, dag_events_[prog_.final_event], 0), "final wait");
-  HIPCHK(hipGetLastError(), "kernel launch");
-  HIPCHK(hipMemcpyAsync(h_flag_, d_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "flag read");
+  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
   stats_.launches = (int)prog_.launches.size() + 1;
+  if (xchg_idx_ < 0) {
+    int rc = enqueue_range(0, prog_.launches.size());
+    if (rc) return rc;
+    return finish_enqueue();
+  }
+  // partitioned: own subtrees, then pack the top-tree block columns
+  if (!xbuf_) return fail(-10, "exchange buffer not set", hipSuccess);
+  int rc = enqueue_range(0, (size_t)xchg_idx_);
+  if (rc) return rc;
+  const Launch& X = prog_.launches[xchg_idx_];
+  if (X.wait0 >= 0) HIPCHK(hipStreamWaitEvent(stream_, dag_events_[X.wait0], 0), "exchange wait");
+  int64_t xo = 0;
+  for (int b : top_bcols_) {
+    const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+    HIPCHK(hipMemcpyAsync(xbuf_ + xo, d_L_ + S.bcols[b].off, sizeof(double) * (size_t)cnt,
+                          hipMemcpyDeviceToDevice, stream_), "pack top tree");
+    xo += cnt;
+  }
+  HIPCHK(hipGetLastError(), "kernel launch");
+  awaiting_exchange_ = true;
+  return 0;
+}
+
+int Engine::sync_phase() {
+  if (status_) return status_;
+  HIPCHK(hipStreamSynchronize(stream_), "stream sync");
+  HIPCHK(hipStreamSynchronize(bulk_), "stream sync");
+  return 0;
+}
+
+int Engine::continue_after_exchange() {
+  if (status_) return status_;
+  if (!awaiting_exchange_) return -10;
+  const Symbolic& S = *S_;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  int64_t xo = 0;
+  for (int b : top_bcols_) {
+    const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+    HIPCHK(hipMemcpyAsync(d_L_ + S.bcols[b].off, xbuf_ + xo, sizeof(double) * (size_t)cnt,
+                          hipMemcpyDeviceToDevice, stream_), "unpack top tree");
+    xo += cnt;
+  }
+  const Launch& X = prog_.launches[xchg_idx_];
+  if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], stream_), "exchange record");
+  int rc = enqueue_range((size_t)xchg_idx_ + 1, prog_.launches.size());
+  if (rc) return rc;
+  rc = finish_enqueue();
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ev1_, stream_), "event");
+  awaiting_exchange_ = false;
   return 0;
 }
 
@@ -181,6 +273,7 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
 int Engine::wait() {
   if (status_) return status_;
   if (!pending_) return 0;
+  if (awaiting_exchange_) return sync_phase();  // not finished: only drain phase 1
   HIPCHK(hipStreamSynchronize(stream_), "stream sync");
   pending_ = false;
   float ms = 0;
@@ -211,7 +304,7 @@ int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<fl
   HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
   *h_flag_ = INT_MAX;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
-  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, S.nnzA);
+  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
   size_t nl = prog_.launches.size();
   std::vector<hipEvent_t> ev(nl + 1);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e), "event create");

@@ -20,6 +20,7 @@ struct EngineOptions {
   int tile = 128;
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
+  int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
 };
 
 struct FactorStats {
@@ -46,6 +47,18 @@ class Engine {
   // spllt_wait for this engine: drain the stream, surface "not positive definite".
   int wait();
   bool pending() const { return pending_; }
+  // ---- multi-GPU (nranks > 1): factor_async* stops after the rank's own
+  // subtrees with the top-tree block columns packed into the exchange buffer;
+  // the caller reduces that buffer across ranks (RCCL all-reduce), then calls
+  // continue_after_exchange() and finally wait().
+  int64_t exchange_elems() const { return xchg_elems_; }
+  int set_exchange_buffer(double* dev_ptr) { xbuf_ = dev_ptr; return 0; }
+  bool awaiting_exchange() const { return awaiting_exchange_; }
+  int sync_phase();                 // drain the streams at the exchange point
+  int continue_after_exchange();
+  const std::vector<int>& owners() const { return owner_; }
+  const std::vector<int>& top_bcols() const { return top_bcols_; }
+  const std::vector<char>& map_keep() const { return map_keep_; }
   int not_posdef_column() const { return npd_col_; }
 
   int download(double* out, int64_t count);  // D2H of the arena
@@ -60,6 +73,8 @@ class Engine {
  private:
   int upload();
   int enqueue_program();
+  int enqueue_range(size_t first, size_t last);
+  int finish_enqueue();
   int enqueue_launch(const Launch& l, bool serial);
   int fail(int code, const char* what, hipError_t e);
 
@@ -76,6 +91,14 @@ class Engine {
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
   bool pending_ = false;
+  bool awaiting_exchange_ = false;
+  int xchg_idx_ = -1;               // index of the L_EXCHANGE launch, -1 = single GPU
+  int64_t xchg_elems_ = 0;
+  double* xbuf_ = nullptr;          // caller-owned device buffer of xchg_elems_ doubles
+  std::vector<int> owner_;          // per node: owning rank or -1 (top tree)
+  std::vector<int> top_bcols_;      // block columns of the top tree, in order
+  std::vector<char> map_keep_;      // per val->L map entry: scattered on this rank?
+  int64_t nmap_ = 0;                // entries of the (filtered) scatter map on the device
   int npd_col_ = -1;
   FactorStats stats_;
 

@@ -100,21 +100,11 @@ struct Builder {
     us.clear();
   }
 
-  bool mine(int s) const {
-    int own = opt.node_owner ? opt.node_owner[s] : -1;
-    if (opt.phase == 1) return own == opt.rank;
-    if (opt.phase == 2) return own < 0;
-    return own < 0 || own == opt.rank;
-  }
-
   void run() {
     P.pw = pw;
     const int nn = S.nnodes;
     int maxlevel = -1;
     for (int s = 0; s < nn; ++s) maxlevel = std::max(maxlevel, S.level[s]);
-    std::vector<std::vector<int>> by_level(maxlevel + 1);
-    for (int s = 0; s < nn; ++s)
-      if (mine(s)) by_level[S.level[s]].push_back(s);
 
     // dinv slots: one per (block column, panel)
     std::vector<int64_t> dinv_slot(S.nbcol() + 1, 0);
@@ -134,6 +124,32 @@ struct Builder {
 
     std::vector<UpdUnit> us;
     int ev_level = -1;  // completion event of the previous level
+    // A partitioned program (multi-GPU) runs the rank's own subtrees first, then
+    // an EXCHANGE marker (the extend-add of the top-tree block columns across
+    // ranks happens there), then the replicated top tree.
+    const bool partitioned = opt.node_owner != nullptr && opt.nranks > 1;
+    const int nphase = partitioned ? 2 : 1;
+    for (int ph = 0; ph < nphase; ++ph) {
+    std::vector<std::vector<int>> by_level(maxlevel + 1);
+    for (int s = 0; s < nn; ++s) {
+      bool take = true;
+      if (partitioned) take = (ph == 0) ? (opt.node_owner[s] == opt.rank) : (opt.node_owner[s] < 0);
+      if (take) by_level[S.level[s]].push_back(s);
+    }
+    if (partitioned && ph == 1) {
+      Launch X;
+      X.kind = L_EXCHANGE;
+      X.level = -1;
+      X.first = X.count = 0;
+      X.tile = 0;
+      X.flops = 0;
+      X.stream = 0;
+      X.wait0 = ev_level;  // everything of phase 1, both streams
+      int ev = P.nevents++;
+      X.record = ev;
+      ev_level = ev;
+      P.launches.push_back(X);
+    }
     for (int lev = 0; lev <= maxlevel; ++lev) {
       const auto& nodes = by_level[lev];
       if (nodes.empty()) continue;
@@ -400,6 +416,7 @@ struct Builder {
         emit_gemm(lev, us, fl, true, e);
       }
     }
+    }  // phases
     P.final_event = ev_level;
   }
 };

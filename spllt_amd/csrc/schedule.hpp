@@ -67,7 +67,7 @@ struct PotrfUnit {
   int flags;         // bit 0: block is already a Cholesky factor, only invert it
 };
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1 };
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2 };
 
 struct Launch {
   int kind;
@@ -99,11 +99,12 @@ struct Program {
 struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
-  int rank = 0;         // multi-GPU: build only this rank's part ...
-  int nranks = 1;       // ... of the subtree partition
-  const int* node_owner = nullptr;  // nnodes: owning rank, or -1 = replicated (top tree)
-  int phase = 0;        // 0 = everything owned/replicated in one program;
-                        // 1 = only nodes owned by `rank`; 2 = only replicated nodes
+  // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree
+  // node, -1 for the (replicated) top tree.  With nranks > 1 the program is
+  // [own subtrees] EXCHANGE [top tree].
+  int rank = 0;
+  int nranks = 1;
+  const int* node_owner = nullptr;
   bool lookahead = true;  // two-stream schedule: panel chain of block column c+1
                           // overlaps the trailing update by block column c
 };

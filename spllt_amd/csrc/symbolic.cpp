@@ -231,6 +231,23 @@ void prune_tree(Symbolic& S, int nth) {
   }
 }
 
+void assign_owners(const Symbolic& S, int nranks, std::vector<int>& owner) {
+  const int nn = S.nnodes;
+  owner.assign(nn, -1);
+  if (nranks < 1) nranks = 1;
+  std::vector<int> roots;
+  for (int s = 0; s < nn; ++s)
+    if (S.small[s] == 1) roots.push_back(s);
+  std::stable_sort(roots.begin(), roots.end(),
+                   [&](int a, int b) { return S.weight[a] > S.weight[b]; });
+  std::vector<int64_t> load(nranks, 0);
+  for (int r : roots) {
+    int p = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    load[p] += S.weight[r];
+    for (int v = S.least_desc[r]; v <= r; ++v) owner[v] = p;
+  }
+}
+
 int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
             const SymOptions& opt, Symbolic& S) {
   S = Symbolic();

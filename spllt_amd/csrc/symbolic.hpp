@@ -97,5 +97,9 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
 void nested_dissection(int n, const std::vector<int64_t>& xadj,
                        const std::vector<int>& adj, int leaf, std::vector<int>& order);
 void prune_tree(Symbolic& S, int nth);
+// Multi-GPU partition from the pruning marks: every pruned subtree (small == 1
+// root and its members) goes to one rank, heaviest first onto the least loaded
+// rank; nodes outside pruned subtrees (the top tree) get owner -1.
+void assign_owners(const Symbolic& S, int nranks, std::vector<int>& owner);
 
 }  // namespace spx

@@ -9,10 +9,15 @@ import scipy.linalg as sl
 MODE_DIRECT, MODE_SCATTER, MODE_TRSM = 0, 1, 2
 
 
-def emulate_program(f, val):
+def emulate_program(f, val, exchange=None, partitioned=False):
+    """exchange(xbuf) -> summed xbuf is called at the EXCHANGE marker of a
+    partitioned (multi-GPU) program with the packed top-tree block columns."""
     info = f.sym_info()
     arena = np.zeros(info["arena"])
     md, ms = f.sym("map_dst"), f.sym("map_src")
+    if partitioned:
+        keep = f.partition("map_keep").astype(bool)
+        md, ms = md[keep], ms[keep]
     arena[md] = np.asarray(val)[ms]
     launches = f.program("launches")
     potrf = f.program("potrf")
@@ -42,6 +47,18 @@ def emulate_program(f, val):
         return out
 
     for kind, level, first, count, tile, _fl, _st, _w0, _w1, _rec in launches:
+        if kind == 2:  # EXCHANGE: pack the top-tree block columns, reduce, unpack
+            top = f.partition("top_bcols")
+            sl_ = [slice(int(bc_off[b]), int(bc_off[b]) + int(f.sym("bcol_nrow")[b]) * int(bc_w[b]))
+                   for b in top]
+            xbuf = np.concatenate([arena[s_] for s_ in sl_]) if sl_ else np.zeros(0)
+            xbuf = exchange(xbuf)
+            o = 0
+            for s_ in sl_:
+                k = s_.stop - s_.start
+                arena[s_] = xbuf[o:o + k]
+                o += k
+            continue
         if kind == 0:
             for q in potrf[first:first + count]:
                 n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])

@@ -268,3 +268,49 @@ def test_fortran_api_kat():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "1.50000000  2.00000000  1.50000000" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_engine_two_ranks_on_one_gpu(world):
+    """Multi-GPU engine path on the one-GPU box: `world` rank-engines run in
+    this process on the same device; the exchange buffers are summed with a
+    torch add (what RCCL all-reduce does across devices).  Every rank must end
+    with its own subtrees + the whole top tree equal to the oracle's L."""
+    torch = _torch()
+    A = matgen.nd_like((10, 9, 8), 2)
+    fs, bufs = [], []
+    for r in range(world):
+        f, val = make_case(A, nb=32, nemin=8, prune=True, ncpu=world, panel_width=16)
+        xel = f.set_partition(r, world)
+        assert xel > 0
+        xb = torch.zeros(xel, dtype=torch.float64, device="cuda")
+        f.set_exchange_buffer(xb.data_ptr())
+        fs.append(f)
+        bufs.append(xb)
+    dval = torch.tensor(val, device="cuda")
+    torch.cuda.synchronize()
+    for f in fs:
+        f.factor_dev(dval.data_ptr())
+        f.wait()
+    total = torch.stack(bufs).sum(dim=0)
+    for xb in bufs:
+        xb.copy_(total)
+    torch.cuda.synchronize()
+    for f in fs:
+        f.continue_after_exchange()
+        f.wait()
+    o, rc = oracle_factor(fs[0], val)
+    assert rc == 0
+    ref = o.arena()
+    mask = lower_mask(fs[0])
+    owner = fs[0].partition("owner")
+    bc_node = fs[0].sym("bcol_node")
+    off, w, nr = fs[0].sym("bcol_off"), fs[0].sym("bcol_width"), fs[0].sym("bcol_nrow")
+    for r, f in enumerate(fs):
+        got = f.get_factor()
+        mine = np.zeros_like(mask)
+        for b in range(len(off)):
+            if owner[bc_node[b]] in (r, -1):
+                mine[off[b]:off[b] + nr[b] * w[b]] = True
+        assert rel_err(got, ref, mask & mine) <= TOL_L
+        assert np.all(got[~mine] == 0.0)

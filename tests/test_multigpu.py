@@ -1,0 +1,98 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo runs of the subtree partition,
+the EXCHANGE step (spllt_amd.multigpu.reduce_exchange_buffer == the production
+all-reduce) and the two-phase program, with the program tables interpreted in
+numpy (tests/emulate.py) instead of executed by HIP."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, case, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emulate import emulate_program
+        from helpers import dense_arena, lower_mask, make_case
+        from spllt_amd import matgen, multigpu
+        A = {"p2d": lambda: matgen.poisson2d(28), "box": lambda: matgen.nd_like((9, 8, 8), 2),
+             "p3d": lambda: matgen.poisson3d(9)}[case]()
+        f, val = make_case(A, nb=16, nemin=8, prune=True, ncpu=world, panel_width=16)
+        xel = f.set_partition(rank, world)
+        owner = f.partition("owner")
+
+        def exchange(xbuf):
+            assert xbuf.size == xel
+            t = torch.from_numpy(xbuf.copy())
+            multigpu.reduce_exchange_buffer(t)
+            return t.numpy()
+
+        got = emulate_program(f, val, exchange=exchange, partitioned=True)
+        exp = dense_arena(f, A)
+        mask = lower_mask(f)
+        # this rank must hold its own subtrees and the whole top tree
+        bc_node = f.sym("bcol_node")
+        off, w, nr = f.sym("bcol_off"), f.sym("bcol_width"), f.sym("bcol_nrow")
+        mine = np.zeros_like(mask)
+        for b in range(len(off)):
+            o = owner[bc_node[b]]
+            if o == rank or o < 0:
+                mine[off[b]:off[b] + nr[b] * w[b]] = True
+        err = np.abs(got - exp)[mask & mine].max() / np.abs(exp).max()
+        untouched = np.all(got[mask & ~mine] == 0.0)
+        nsub = int((f.sym("small") == 1).sum())
+        ntop = int((owner < 0).sum())
+        L = f.program("launches")
+        ret[rank] = (float(err), bool(untouched), nsub, ntop, int((L[:, 0] == 2).sum()),
+                     sorted(set(owner.tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("p2d", 2), ("box", 2), ("p3d", 3)])
+def test_partitioned_program_over_gloo(case, world):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        err, untouched, nsub, ntop, nx, owners = ret[rank]
+        assert err < 1e-13, (rank, err)
+        assert untouched            # other ranks' subtrees are never written here
+        assert nsub >= world and ntop >= 1
+        assert nx == 1              # exactly one exchange point
+        assert set(owners) == set(range(world)) | {-1}
+
+
+def test_owner_assignment_is_balanced_and_covers_subtrees():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_case
+    from spllt_amd import matgen
+    A = matgen.poisson2d(48)
+    f, _ = make_case(A, nb=32, nemin=16, prune=True, ncpu=4)
+    f.set_partition(0, 4)
+    owner, small, w = f.partition("owner"), f.sym("small"), f.sym("weight")
+    sparent = f.sym("sparent")
+    nn = len(owner)
+    load = np.zeros(4)
+    for s in range(nn):
+        if small[s] == 0:
+            assert owner[s] == -1
+        else:
+            assert 0 <= owner[s] < 4
+            p = sparent[s]
+            if small[s] < 0:
+                assert owner[p] == owner[s]   # members follow their subtree root
+        if small[s] == 1:
+            load[owner[s]] += w[s]
+    assert load.min() > 0.5 * load.max()
