@@ -110,8 +110,15 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal on a one-GPU box: SPLLT_DIST_BACKEND=gloo SPLLT_SINGLE_DEVICE=1
+        # puts every rank on device 0 and reduces through gloo
+        backend = os.environ.get("SPLLT_DIST_BACKEND", "nccl")
+        dev = 0 if os.environ.get("SPLLT_SINGLE_DEVICE") else local_rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     from spllt_amd import api

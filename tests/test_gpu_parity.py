@@ -314,3 +314,22 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
                 mine[off[b]:off[b] + nr[b] * w[b]] = True
         assert rel_err(got, ref, mask & mine) <= TOL_L
         assert np.all(got[~mine] == 0.0)
+
+
+def test_golden_vectors_gpu():
+    """tests/golden/dense_chol_*.npz (dense LAPACK factors for a fixed order):
+    the HIP path must reproduce them to 1e-12 and solve to x = 1."""
+    import glob
+    import os
+    from test_golden import expected_arena
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dense_chol_*.npz")))
+    assert paths
+    for path in paths:
+        g = np.load(path)
+        f = api.Factorization(int(g["n"]), g["ptr"], g["row"], nb=16, nemin=4, prune_tree=False,
+                              order=g["order_in"], panel_width=16)
+        exp, _ = expected_arena(f, g)
+        got = f.factor(g["val"]).wait().get_factor()
+        mask = lower_mask(f)
+        assert np.abs(got - exp)[mask].max() <= TOL_L * np.abs(exp).max()
+        np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
