@@ -135,7 +135,8 @@ def main():
 
     t0 = time.time()
     f = api.Factorization(n, ptr, row, nb=nb, nemin=32, prune_tree=False, order=order,
-                          panel_width=args.panel)
+                          panel_width=args.panel,
+                          engine_flags=int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")))
     t_analyse = time.time() - t0
     si = f.sym_info()
     flops = float(si["flops"])

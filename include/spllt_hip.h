@@ -93,7 +93,9 @@ int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
 int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_t capacity);
 
 /* engine knobs (before the first spllt_factor on this fkeep); flags: bit 0 =
- * replay through a hipGraph, bit 1 = single-stream program (no lookahead) */
+ * replay through a hipGraph, bit 1 = single-stream program (no lookahead),
+ * bit 2 = fused strip-TRSM kernel + tile-level lookahead on latency-bound levels
+ * (measured slower than the default on MI355X, kept for experiments) */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------
@@ -126,7 +128,7 @@ int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, do
                            int *launches);
 /* program export for tests: "launches" (int64 x 10 per launch: kind, level,
  * first, count, tile, flops, stream, wait0, wait1, record), "potrf" (PotrfUnit bytes), "units" (UpdUnit
- * bytes), "tiles" (UpdTile bytes), "relpos" (int32).  Returns byte length. */
+ * bytes), "tiles" (UpdTile bytes), "strips" (StripUnit bytes), "relpos" (int32).  Returns byte length. */
 int64_t spllt_hip_program_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 /* per-launch device time (ms) of one profiled factorization; returns #launches */
 int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int capacity);

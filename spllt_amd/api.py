@@ -27,6 +27,8 @@ UPD_UNIT_DTYPE = np.dtype([
     ("dinv_ld", "<i4"), ("lower", "<i4"), ("b_bcol0", "<i4"), ("b_seg_r0", "<i4"),
     ("pad_", "<i4"), ("pad2_", "<i4")])
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
+STRIP_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("row0", "<i4"),
+                             ("nrows", "<i4"), ("pw", "<i4")])
 POTRF_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("n", "<i4"),
                              ("gcol", "<i4"), ("flags", "<i4")])
 
@@ -128,6 +130,8 @@ class Factorization:
             return raw.view(POTRF_UNIT_DTYPE)
         if name == "relpos":
             return raw.view(np.int32)
+        if name == "strips":
+            return raw.view(STRIP_UNIT_DTYPE)
         if name == "dinv_size":
             return int(raw.view(np.int64)[0])
         return raw

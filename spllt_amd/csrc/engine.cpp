@@ -4,6 +4,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -56,6 +57,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.pw = opt_.pw;
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
+  so.fused_strip = opt_.fused_strip;
   if (opt_.nranks > 1) {
     assign_owners(*S_, opt_.nranks, owner_);
     so.node_owner = owner_.data();
@@ -79,7 +81,23 @@ int Engine::upload() {
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");
   HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
-  HIPCHK(hipStreamCreateWithPriority(&bulk_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+  // Optional CU reservation (experiment knob SPLLT_HIP_RESERVE_CUS=n): the bulk
+  // stream is masked off n CUs so that the latency-critical panel kernels
+  // always find a free CU instead of queueing behind bulk workgroups.
+  int reserve = 0;
+  if (const char* e = std::getenv("SPLLT_HIP_RESERVE_CUS")) reserve = std::atoi(e);
+  if (reserve > 0) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_), "device props");
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    // reserve CUs spread over the XCDs (CU ids are dealt round-robin to XCDs)
+    for (int cu = 0; cu < ncu; ++cu)
+      if (cu >= reserve) mask[cu / 32] |= 1u << (cu % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&bulk_, (uint32_t)mask.size(), mask.data()), "cu-mask stream");
+  } else {
+    HIPCHK(hipStreamCreateWithPriority(&bulk_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+  }
   dag_events_.resize(prog_.nevents);
   for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
@@ -119,6 +137,7 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
   HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
   HIPCHK(dev_upload(&d_potrf_, prog_.potrf_units), "upload potrf units");
+  HIPCHK(dev_upload(&d_strips_, prog_.strip_units), "upload strip units");
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
@@ -134,7 +153,7 @@ Engine::~Engine() {
   if (graph_exec_) hipGraphExecDestroy(graph_exec_);
   if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
   if (ev0_) hipEventDestroy(ev0_);
@@ -152,6 +171,8 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
   if (l.count > 0 && l.kind != L_EXCHANGE) {
     if (l.kind == L_POTRF)
       launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
+    else if (l.kind == L_STRIP)
+      launch_strip(st, l.tile, d_tiles_ + l.first, l.count, d_strips_, d_L_, d_dinv_);
     else
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
                     d_relpos_, d_rlist_, d_dinv_);

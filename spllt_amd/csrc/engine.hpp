@@ -20,6 +20,7 @@ struct EngineOptions {
   int tile = 128;
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
+  bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
 };
 
@@ -112,6 +113,7 @@ class Engine {
   UpdUnit* d_units_ = nullptr;
   UpdTile* d_tiles_ = nullptr;
   PotrfUnit* d_potrf_ = nullptr;
+  StripUnit* d_strips_ = nullptr;
   int* d_relpos_ = nullptr;
   int* d_rlist_ = nullptr;
   int* d_flag_ = nullptr;

@@ -54,6 +54,20 @@ __global__ __launch_bounds__(256) void k_scatter_val(double* __restrict__ L,
 constexpr int TLD = 66;   // LDS row stride (doubles): conflict-free MFMA operand reads
 constexpr int DLD = 17;
 
+template <int LD>
+__device__ inline d4 ld_c_s(const double* M, int row0, int col0, int lane) {
+  const int lq = lane >> 4, lr = lane & 15;
+  d4 c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = M[(row0 + lq + 4 * r) * LD + col0 + lr];
+  return c;
+}
+template <int LD>
+__device__ inline void st_c_s(double* M, int row0, int col0, int lane, d4 c) {
+  const int lq = lane >> 4, lr = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[(row0 + lq + 4 * r) * LD + col0 + lr] = c[r];
+}
 __device__ inline d4 ld_c(const double* M, int row0, int col0, int lane) {
   const int lq = lane >> 4, lr = lane & 15;
   d4 c;
@@ -457,6 +471,128 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
 }
 
 // ---------------------------------------------------------------------------
+// a12 for all sub-diagonal rows of a block column in one launch: each
+// workgroup owns a strip of RS rows and runs the blocked substitution over the
+// block column's panels with the strip resident in LDS:
+//     X_p = (A_p - sum_{q<p} X_q L_pq^T) * inv(L_pp)^T ,   p = 0, 1, ...
+// L_pq (blocks of the factored diagonal tile) and inv(L_pp) (dinv scratch) are
+// staged through LDS; all products run on v_mfma_f64_16x16x4_f64, wave w owning
+// the 16-column tile w of the current panel.  Replaces the 2*np-1 dependent
+// TRSM/UPDATE launches per block column of the unfused path.
+// ---------------------------------------------------------------------------
+constexpr int SLD = 66;  // staging block row stride
+
+// 64 x 64 staging block: thread t fetches 16 consecutive doubles of row t/4
+// with all loads in flight at once (clamped addresses, zero-filled afterwards)
+__device__ inline void stage64(double* __restrict__ Ls, const double* __restrict__ src, int ld,
+                               int nrow, int ncol, int tid) {
+  const int j = tid >> 2, c = (tid & 3) * 16;
+  const int jc = j < nrow ? j : nrow - 1;
+  double v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = c + e < ncol ? c + e : ncol - 1;
+    v[e] = src[(int64_t)jc * ld + k];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) Ls[j * SLD + c + e] = (j < nrow && c + e < ncol) ? v[e] : 0.0;
+}
+
+template <int RS, int WMAX>
+__global__ __launch_bounds__(256) void k_trsm_strip(const UpdTile* __restrict__ tiles,
+                                                    const StripUnit* __restrict__ units,
+                                                    double* __restrict__ L,
+                                                    const double* __restrict__ dinv) {
+  constexpr int XLD = WMAX + 2;
+  constexpr int RT = RS / 16;
+  constexpr int TPR = 256 / RS;          // threads per strip row
+  __shared__ double Xs[RS * XLD];
+  __shared__ double Ls[64 * SLD];
+  const UpdTile tl = tiles[blockIdx.x];
+  const StripUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int w = u.ld, pw = u.pw;
+  const int wpad = (w + 15) & ~15;
+  const int r0 = u.row0 + (int)tl.ti * RS;
+  const int nr = min(RS, u.row0 + u.nrows - r0);
+  double* A = L + u.off;
+  // strip load: thread t owns row t/TPR, 16-column chunks (t%TPR), (t%TPR)+TPR, ...
+  const int si = tid / TPR, sc = (tid % TPR) * 16;
+  {
+    const double* arow = A + (int64_t)(r0 + (si < nr ? si : nr - 1)) * w;
+    for (int c = sc; c < wpad; c += TPR * 16) {
+      double v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = arow[c + e < w ? c + e : w - 1];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Xs[si * XLD + c + e] = (si < nr && c + e < w) ? v[e] : 0.0;
+    }
+  }
+  const int np = (w + pw - 1) / pw;
+  int64_t slot = u.dinv_off;
+  for (int p = 0; p < np; ++p) {
+    const int c0 = p * pw;
+    const int pn = min(pw, w - c0);
+    const bool act = wave * 16 < pn;   // this wave's 16-column tile exists in the panel
+    d4 acc[RT];
+    __syncthreads();                   // Xs complete (initial load / previous panel's X)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (act) acc[rt] = ld_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane);
+    for (int q = 0; q < p; ++q) {
+      __syncthreads();                 // previous staging block fully consumed
+      stage64(Ls, A + (int64_t)c0 * w + q * pw, w, pn, pw, tid);
+      __syncthreads();
+      if (act) {
+        for (int k = 0; k < pw; k += 4) {
+          const double b = Ls[(wave * 16 + lr) * SLD + k + lq];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const double a = -Xs[(rt * 16 + lr) * XLD + q * pw + k + lq];
+            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (act) st_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane, acc[rt]);
+    // stage inv(L_pp), zero-padded to 64 x 64
+    stage64(Ls, dinv + slot, pn, pn, pn, tid);
+    __syncthreads();
+    d4 res[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) res[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (act) {
+      const int kend = (pn + 3) & ~3;
+      for (int k = 0; k < kend; k += 4) {
+        const double b = Ls[(wave * 16 + lr) * SLD + k + lq];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const double a = Xs[(rt * 16 + lr) * XLD + c0 + k + lq];
+          res[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, res[rt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                   // every wave has read the panel before it is overwritten
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (act) st_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane, res[rt]);
+    slot += (int64_t)pn * pn;
+  }
+  __syncthreads();
+  if (si < nr) {
+    double* arow = A + (int64_t)(r0 + si) * w;
+    for (int c = sc; c < w; c += TPR * 16) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (c + e < w) arow[c + e] = Xs[si * XLD + c + e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // a26: extend-add of a generated element window into an ancestor tile,
 // dest[pos_r(i)][pos_c(j)] -= src[i][j]; positions found by binary search in
 // the destination's (sorted) index lists.
@@ -540,9 +676,21 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
   if (tile == 128)
     hipLaunchKernelGGL(k_update<128>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
                        bc_off, bc_w, L, relpos, rlist, dinv);
-  else
+  else if (tile == 64)
     hipLaunchKernelGGL(k_update<64>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
                        bc_off, bc_w, L, relpos, rlist, dinv);
+  else
+    hipLaunchKernelGGL(k_update<32>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
+                       bc_off, bc_w, L, relpos, rlist, dinv);
+}
+
+void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
+                  const StripUnit* units, double* L, const double* dinv) {
+  if (count <= 0) return;
+  if (rs == 32)
+    hipLaunchKernelGGL((k_trsm_strip<32, 320>), dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
+  else
+    hipLaunchKernelGGL((k_trsm_strip<16, 896>), dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
 }
 
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,

@@ -21,6 +21,9 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,
                           double* dest, int ldd);
 
+// rs = rows per strip: 32 (block column width <= 320) or 16 (<= 896)
+void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
+                  const StripUnit* units, double* L, const double* dinv);
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
                           const int* col_list, int cls, int ndiag, const double* buffer);
 

@@ -40,6 +40,7 @@ struct OpsBatch {
     UpdUnit* d_units = nullptr;
     UpdTile* d_tiles = nullptr;
     PotrfUnit* d_potrf = nullptr;
+    StripUnit* d_strips = nullptr;
     double* d_dinv = nullptr;
     int* d_flag = dev_flag;
     bool own_flag = false;
@@ -54,6 +55,7 @@ struct OpsBatch {
     up((void**)&d_units, P.units.data(), P.units.size() * sizeof(UpdUnit));
     up((void**)&d_tiles, P.tiles.data(), P.tiles.size() * sizeof(UpdTile));
     up((void**)&d_potrf, P.potrf_units.data(), P.potrf_units.size() * sizeof(PotrfUnit));
+    up((void**)&d_strips, P.strip_units.data(), P.strip_units.size() * sizeof(StripUnit));
     if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * std::max<int64_t>(1, P.dinv_size));
     if (e == hipSuccess && !d_flag) {
       own_flag = true;
@@ -64,8 +66,11 @@ struct OpsBatch {
     if (e == hipSuccess) {
       double* base = nullptr;  // table offsets are absolute (address / 8)
       for (const Launch& l : P.launches) {
+        if (l.count <= 0) continue;
         if (l.kind == L_POTRF)
           launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag);
+        else if (l.kind == L_STRIP)
+          launch_strip(st, l.tile, d_tiles + l.first, l.count, d_strips, base, d_dinv);
         else
           launch_update(st, l.tile, d_tiles + l.first, l.count, d_units, d_off, d_w, base, relpos,
                         rlist, d_dinv);
@@ -74,7 +79,7 @@ struct OpsBatch {
       hipError_t e2 = hipStreamSynchronize(st);
       if (e == hipSuccess) e = e2;
     }
-    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_dinv);
+    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_strips); hipFree(d_dinv);
     if (own_flag) hipFree(d_flag);
     if (e != hipSuccess) {
       std::fprintf(stderr, "spllt-hip: operator failed: %s\n", hipGetErrorString(e));
@@ -131,6 +136,7 @@ int spllt_factor_diag_block_hip(void* stream, int m, int n, double* bc, int* dev
   one_bcol_symbolic(S, m, n, abs_off(bc));
   OpsBatch B;
   ScheduleOptions so;
+  so.lookahead = false;  // one stream, program order
   build_program(S, so, B.P);
   B.bc_off = {S.bcols[0].off};
   B.bc_w = {n};

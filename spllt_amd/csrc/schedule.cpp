@@ -59,11 +59,25 @@ struct Builder {
       }
       return;
     }
-    std::vector<UpdTile> t128, t64;
+    std::vector<UpdTile> t128, t64, t32;
+    // Latency-bound phases (a handful of tiles: one 128-tile with K = 256 is
+    // ~60 us of dependent MFMAs on one CU) are cut into smaller tiles so that
+    // more CUs share the work: 64-tiles below 64 large tiles, 32-tiles when
+    // even those would leave most of the chip idle.
+    int64_t n128 = 0, n64 = 0;
+    for (auto& u : us) {
+      if (u.mode == MODE_TRSM) continue;
+      if (pick_tile(u.M, u.N) == 128) n128 += (int64_t)cdiv(u.M, 128) * cdiv(u.N, 128);
+      n64 += (int64_t)cdiv(u.M, 64) * cdiv(u.N, 64);
+    }
+    const bool small_launch = n128 > 0 && n128 < 64;
+    const bool tiny_launch = n64 > 0 && n64 <= 192;
     for (auto& u : us) {
       int uid = (int)P.units.size();
       P.units.push_back(u);
       int T = (u.mode == MODE_TRSM) ? (u.N > 64 ? 128 : pick_tile(u.M, u.N)) : pick_tile(u.M, u.N);
+      if (small_launch && u.mode != MODE_TRSM) T = 64;
+      if (tiny_launch && u.mode != MODE_TRSM) T = 32;
       const bool low = lower && u.lower;
       if (T == 128 && u.mode != MODE_TRSM) {
         // 128-wide tile columns, except a trailing remainder of <= 64 columns
@@ -74,26 +88,32 @@ struct Builder {
         if (full > 0) add_tiles(t128, uid, u, 128, low, 0, full);
         if (full < u.N) add_tiles(t64, uid, u, 64, low, full, u.N);
       } else {
-        add_tiles(T == 128 ? t128 : t64, uid, u, T, low, 0, u.N);
+        add_tiles(T == 128 ? t128 : (T == 64 ? t64 : t32), uid, u, T, low, 0, u.N);
       }
     }
-    double ntot = (double)t128.size() * 4 + (double)t64.size();
-    for (int pass = 0; pass < 2; ++pass) {
-      auto& tv = pass == 0 ? t128 : t64;
+    double ntot = (double)t128.size() * 16 + (double)t64.size() * 4 + (double)t32.size();
+    std::vector<UpdTile>* lists[3] = {&t128, &t64, &t32};
+    const int edges[3] = {128, 64, 32};
+    int first_nonempty = -1, last_nonempty = -1;
+    for (int i = 0; i < 3; ++i)
+      if (!lists[i]->empty()) {
+        if (first_nonempty < 0) first_nonempty = i;
+        last_nonempty = i;
+      }
+    for (int pass = 0; pass < 3; ++pass) {
+      auto& tv = *lists[pass];
       if (tv.empty()) continue;
       Launch L;
       L.kind = L_GEMM;
       L.level = level;
       L.first = (int64_t)P.tiles.size();
       L.count = (int64_t)tv.size();
-      L.tile = pass == 0 ? 128 : 64;
-      L.flops = flops * ((double)tv.size() * (pass == 0 ? 4 : 1)) / std::max(1.0, ntot);
+      L.tile = edges[pass];
+      L.flops = flops * ((double)tv.size() * (edges[pass] / 32) * (edges[pass] / 32)) / std::max(1.0, ntot);
       L.stream = e.stream;
-      const bool first_pass = (pass == 0) || t128.empty();
-      const bool last_pass = (pass == 1) || t64.empty();
-      L.wait0 = first_pass ? e.wait0 : -1;
-      L.wait1 = first_pass ? e.wait1 : -1;
-      L.record = last_pass ? e.record : -1;
+      L.wait0 = pass == first_nonempty ? e.wait0 : -1;
+      L.wait1 = pass == first_nonempty ? e.wait1 : -1;
+      L.record = pass == last_nonempty ? e.record : -1;
       P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
       P.launches.push_back(L);
     }
@@ -159,12 +179,38 @@ struct Builder {
       bool first_of_level = true;   // first panel-stream launch waits for the previous level
       int evB_prev = -1;            // bulk event of step c-1 (trailing update of c-1 -> c+1..)
       int evP_last = -1;            // panel event of the last finished step
+      int evB1_prev = -1;           // bulk event: rest rows of block column c updated by c-1
+      // The fused strip kernel shortens the panel chain (1 launch instead of
+      // 2*np-1 per block column) but runs one workgroup per CU; it pays where
+      // the level is latency-bound (few, large nodes), not where thousands of
+      // strips would queue.  Use it when all strips of a step fit in ~2 rounds.
+      bool fs = la && opt.fused_strip;
+      if (fs) {
+        int64_t worst = 0;
+        for (int c = 0; c < maxnc; ++c) {
+          int64_t strips = 0;
+          for (int s : nodes) {
+            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c >= nc) continue;
+            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
+            if (B.nrow > B.width) strips += cdiv(B.nrow - B.width, B.width <= 320 ? 32 : 16);
+          }
+          worst = std::max(worst, strips);
+        }
+        fs = worst <= opt.strip_limit;
+      }
       for (int c = 0; c < maxnc; ++c) {
         int maxp = 0;
         for (int s : nodes) {
           int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
           if (c < nc) maxp = std::max(maxp, cdiv(S.bcols[S.node_bcol0[s] + c].width, pw));
         }
+        // With the fused strip kernel the panel chain only walks the diagonal
+        // tile (rows < width); the rows below are solved by one k_trsm_strip
+        // launch once every panel of the tile is factored.
+        auto chain_rows = [&](const BlockCol& B) {
+          return (fs && B.width <= 896) ? std::min(B.nrow, B.width) : B.nrow;
+        };
         for (int p = 0; p < maxp; ++p) {
           // (1) left-looking update of panel p by the previous panels of the block column
           double fl = 0;
@@ -178,8 +224,8 @@ struct Builder {
               if (c0 >= B.width) continue;
               int pn = std::min(pw, B.width - c0);
               UpdUnit u{};
-            u.b_bcol0 = -1;
-            u.lower = 1;
+              u.b_bcol0 = -1;
+              u.lower = 1;
               u.mode = MODE_DIRECT;
               u.d_off = B.off;
               u.d_ld = B.width;
@@ -191,7 +237,7 @@ struct Builder {
               u.seg_stride = nb;
               u.src_r0 = B.r0 + c0;
               u.src_c0 = B.r0 + c0;
-              u.M = B.nrow - c0;
+              u.M = chain_rows(B) - c0;
               u.N = pn;
               u.k0 = 0;
               u.klen = c0;
@@ -247,11 +293,10 @@ struct Builder {
             int c0 = p * pw;
             if (c0 >= B.width) continue;
             int pn = std::min(pw, B.width - c0);
-            int rows = B.nrow - (c0 + pn);
+            int rows = chain_rows(B) - (c0 + pn);
             if (rows <= 0) continue;
             UpdUnit u{};
             u.b_bcol0 = -1;
-            u.lower = 1;
             u.mode = MODE_TRSM;
             u.lower = 0;
             u.d_off = B.off;
@@ -278,18 +323,61 @@ struct Builder {
           P.flops_trsm += fl;
           emit_gemm(lev, us, fl, false);
         }
+        // (3s) fused strip TRSM of all rows below the diagonal tile
+        if (fs) {
+          for (int rs : {32, 16}) {
+            Launch L;
+            L.kind = L_STRIP;
+            L.level = lev;
+            L.first = (int64_t)P.tiles.size();
+            L.tile = rs;
+            double fl = 0;
+            for (int s : nodes) {
+              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              if (B.width > 896 || B.nrow <= B.width) continue;
+              if ((B.width <= 320 ? 32 : 16) != rs) continue;
+              StripUnit q{};
+              q.off = B.off;
+              q.dinv_off = dinv_slot[b];
+              q.ld = B.width;
+              q.row0 = B.width;
+              q.nrows = B.nrow - B.width;
+              q.pw = pw;
+              int uid = (int)P.strip_units.size();
+              P.strip_units.push_back(q);
+              for (int t = 0; t < cdiv(q.nrows, rs); ++t) {
+                UpdTile tt;
+                tt.unit = uid;
+                tt.ti = (short)t;
+                tt.tj = 0;
+                P.tiles.push_back(tt);
+              }
+              fl += (double)q.nrows * B.width * B.width;
+            }
+            L.count = (int64_t)P.tiles.size() - L.first;
+            L.flops = fl;
+            L.stream = 0;
+            L.wait0 = evB1_prev;  // the rest rows were last written by the bulk stream
+            P.flops_trsm += fl;
+            if (L.count > 0) P.launches.push_back(L);
+          }
+        }
         // (4) right-looking update of the node's later block columns, K = blkn.
-        // With lookahead the update of block column c+1 stays on the panel
-        // stream (it gates the next panel chain) and the rest goes to the bulk
-        // stream, where it overlaps the panel chain of block column c+1.
+        // With lookahead the part that gates the next panel chain stays on the
+        // panel stream (block column c+1, or only its diagonal tile when the
+        // strip kernel is used) and the rest goes to the bulk stream, where it
+        // overlaps the panel chain of block column c+1.
         int evP = -1;
         if (la) {
           evP = P.nevents++;
           P.launches.back().record = evP;  // last launch of the panel chain of step c
           evP_last = evP;
         }
-        std::vector<UpdUnit> us_bulk;
-        double fl = 0, fl_bulk = 0;
+        std::vector<UpdUnit> us_bulk, us_rest;
+        double fl = 0, fl_bulk = 0, fl_rest = 0;
         for (int s : nodes) {
           int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
           if (c + 1 >= nc) continue;
@@ -316,11 +404,28 @@ struct Builder {
             u.k0 = 0;
             u.klen = B.width;
             const double f1 = 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
-            if (la && jj > c + 1) { us_bulk.push_back(u); fl_bulk += f1; }
-            else { us.push_back(u); fl += f1; }
+            if (la && jj > c + 1) {
+              us_bulk.push_back(u);
+              fl_bulk += f1;
+            } else if (fs && jj == c + 1 && D.width <= 896 && D.nrow > D.width) {
+              // split: diagonal tile of block column c+1 (panel stream) / rows below (bulk)
+              UpdUnit ud = u, ur = u;
+              ud.M = D.width;
+              ur.d_row0 = D.width;
+              ur.src_r0 = D.r0 + D.width;
+              ur.M = D.nrow - D.width;
+              const double fd = 2.0 * B.width * ((double)ud.M * ud.N - 0.5 * ud.N * (ud.N - 1));
+              us.push_back(ud);
+              fl += fd;
+              us_rest.push_back(ur);
+              fl_rest += f1 - fd;
+            } else {
+              us.push_back(u);
+              fl += f1;
+            }
           }
         }
-        P.flops_update += fl + fl_bulk;
+        P.flops_update += fl + fl_bulk + fl_rest;
         if (!la) {
           emit_gemm(lev, us, fl);
         } else {
@@ -328,18 +433,31 @@ struct Builder {
           e0.stream = 0;
           e0.wait0 = evB_prev;
           if (!us.empty()) emit_gemm(lev, us, fl, true, e0);
+          int evB1 = -1;
+          bool waited = false;
+          if (!us_rest.empty()) {
+            Edge e1;
+            e1.stream = 1;
+            e1.wait0 = evP;
+            waited = true;
+            evB1 = P.nevents++;
+            e1.record = evB1;
+            emit_gemm(lev, us_rest, fl_rest, true, e1);
+          }
           int evB = -1;
           if (!us_bulk.empty()) {
             Edge e1;
             e1.stream = 1;
-            e1.wait0 = evP;
+            e1.wait0 = waited ? -1 : evP;
             evB = P.nevents++;
             e1.record = evB;
             emit_gemm(lev, us_bulk, fl_bulk, true, e1);
           }
           evB_prev = evB;
+          evB1_prev = evB1;
         }
       }
+
       // (5) inter-node updates of the whole level (update_between + scatter)
       double fl = 0;
       for (int s : nodes) {

@@ -67,7 +67,18 @@ struct PotrfUnit {
   int flags;         // bit 0: block is already a Cholesky factor, only invert it
 };
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2 };
+// All sub-diagonal rows of one block column: X = A * inv(L_tile)^T by blocked
+// substitution over the block column's panels inside ONE kernel (k_trsm_strip).
+struct StripUnit {
+  int64_t off;       // arena offset of the block column
+  int64_t dinv_off;  // dinv slot of panel 0 (the panels' slots are consecutive)
+  int ld;            // block column width w
+  int row0;          // first stored row of the region (= w: the rows below the diagonal tile)
+  int nrows;         // rows in the region
+  int pw;            // panel width
+};
+
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3 };
 
 struct Launch {
   int kind;
@@ -88,6 +99,7 @@ struct Program {
   std::vector<PotrfUnit> potrf_units;
   std::vector<UpdUnit> units;
   std::vector<UpdTile> tiles;
+  std::vector<StripUnit> strip_units;  // L_STRIP launches: tiles[].unit indexes this, .ti = strip
   std::vector<Launch> launches;
   std::vector<int> relpos;      // per (node, touched ancestor): positions of the node's rows in the ancestor's row list
   int64_t dinv_size = 0;        // doubles
@@ -107,6 +119,8 @@ struct ScheduleOptions {
   const int* node_owner = nullptr;
   bool lookahead = true;  // two-stream schedule: panel chain of block column c+1
                           // overlaps the trailing update by block column c
+  bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
+  int strip_limit = 512;    // ... on levels whose steps have at most this many strips
 };
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);

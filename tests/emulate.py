@@ -59,6 +59,19 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 arena[s_] = xbuf[o:o + k]
                 o += k
             continue
+        if kind == 3:  # fused strip TRSM: rows below the diagonal tile, all panels
+            strips = f.program("strips")
+            rs = int(tile)
+            for t in tiles[first:first + count]:
+                q = strips[int(t["unit"])]
+                w, off = int(q["ld"]), int(q["off"])
+                r0 = int(q["row0"]) + int(t["ti"]) * rs
+                nr = min(rs, int(q["row0"]) + int(q["nrows"]) - r0)
+                Lt = np.tril(arena[off:off + w * w].reshape(w, w))
+                rows = arena[off + r0 * w: off + (r0 + nr) * w].reshape(nr, w)
+                arena[off + r0 * w: off + (r0 + nr) * w] = sl.solve_triangular(
+                    Lt, rows.T, lower=True).T.ravel()
+            continue
         if kind == 0:
             for q in potrf[first:first + count]:
                 n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])

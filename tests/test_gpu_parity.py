@@ -333,3 +333,14 @@ def test_golden_vectors_gpu():
         mask = lower_mask(f)
         assert np.abs(got - exp)[mask].max() <= TOL_L * np.abs(exp).max()
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("flags", [2, 4])
+def test_engine_variants_match_oracle(flags):
+    """single-stream program (2) and fused strip-TRSM + tile lookahead (4)."""
+    A = matgen.nd_like((12, 11, 10), 2)
+    f, val = make_case(A, nb=64, nemin=16, panel_width=32, engine_flags=flags)
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val)
+    assert rc == 0
+    assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L

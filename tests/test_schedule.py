@@ -117,35 +117,58 @@ def sparent_of(f, a, _cache={}):
 
 
 def _access_sets(f):
-    """Per launch: (reads, writes, atomics) as sets of block-column ids, plus
-    dinv slots (offset by nbcol) -- the granularity at which the stream DAG
-    must order conflicting launches."""
+    """Per launch: (reads, writes, atomics) as sets of resources.  A block
+    column b is two resources: 2b = its diagonal-tile rows (stored rows <
+    width), 2b+1 = the rows below; 2*nbcol + b = the dinv slots of b.  This is
+    the granularity at which the stream DAG must order conflicting launches."""
     launches = f.program("launches")
     potrf, units, tiles = f.program("potrf"), f.program("units"), f.program("tiles")
-    off = f.sym("bcol_off")
+    strips = f.program("strips")
+    off, bw = f.sym("bcol_off"), f.sym("bcol_width")
     nbc = len(off)
+
+    def parts(b, r0, cnt):
+        out = set()
+        if cnt <= 0:
+            return out
+        if r0 < bw[b]:
+            out.add(2 * b)
+        if r0 + cnt > bw[b]:
+            out.add(2 * b + 1)
+        return out
+
     out = []
     for kind, level, first, count, tile, _fl, st, w0, w1, rec in launches:
         R, W, At = set(), set(), set()
         if kind == 0:
             for q in potrf[first:first + count]:
                 b = int(np.searchsorted(off, q["off"], side="right") - 1)
-                W.add(b)
-                R.add(b)
-                W.add(nbc + int(q["dinv_off"]))
-        else:
+                W.add(2 * b)
+                R.add(2 * b)
+                W.add(2 * nbc + b)
+        elif kind == 3:
+            for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
+                q = strips[uid]
+                b = int(np.searchsorted(off, q["off"], side="right") - 1)
+                R |= {2 * b, 2 * nbc + b}
+                W.add(2 * b + 1)
+        elif kind == 1:
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 u = units[uid]
                 db = int(np.searchsorted(off, u["d_off"], side="right") - 1)
                 for sg in range(int(u["nseg"])):
-                    R.add(int(u["src_bcol0"]) + sg)
+                    sb = int(u["src_bcol0"]) + sg
+                    sh = int(u["seg_r0"]) + sg * int(u["seg_stride"])
+                    R |= parts(sb, int(u["src_r0"]) - sh, int(u["M"]))
+                    if u["mode"] != 2:
+                        R |= parts(sb, int(u["src_c0"]) - sh, int(u["N"]))
                 if u["mode"] == 2:
-                    R.add(nbc + int(u["dinv_off"]))
-                    W.add(db)
+                    R.add(2 * nbc + db)
+                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
                 elif u["mode"] == 1:
-                    At.add(db)
+                    At |= {2 * db, 2 * db + 1}
                 else:
-                    W.add(db)
+                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
         out.append((R, W, At))
     return launches, out
 
@@ -153,15 +176,17 @@ def _access_sets(f):
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
                                         (lambda: matgen.poisson3d(9), 24, 8)])
-def test_stream_dag_orders_every_conflict(gen, nb, pw):
+@pytest.mark.parametrize("flags", [0, 4])
+def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     """Two-stream lookahead program: any two launches that touch the same block
     column (write/write, read/write, atomic/plain) must be ordered by stream
     order or an event edge; concurrent atomics into one destination are fine."""
     A = gen()
-    f, val = make_case(A, nb=nb, nemin=8, panel_width=pw)
+    f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
     launches, acc = _access_sets(f)
     n = len(launches)
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
+    assert ((launches[:, 0] == 3).any()) == (flags == 4), "fused strip launches only with flag 4"
     rec_at = {}
     last_in_stream = {}
     before = [0] * n  # bitset of launches that happen-before launch i
@@ -196,5 +221,17 @@ def test_single_stream_program_has_no_events():
     f, val = make_case(A, nb=8, nemin=4, engine_flags=2)
     L = f.program("launches")
     assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all()
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+@pytest.mark.parametrize("flags", [0, 4, 2, 6])
+def test_program_variants_agree(flags):
+    """fused strip / per-panel TRSM, two-stream / single-stream programs all
+    reproduce the same factor (interpreted in numpy)."""
+    A = matgen.nd_like((8, 7, 7), 2)
+    f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
+    L = f.program("launches")
+    assert ((L[:, 0] == 3).any()) == (flags == 4)   # strip kernel needs the two-stream program
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
