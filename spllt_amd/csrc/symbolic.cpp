@@ -315,28 +315,49 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
     sm[s] = cc[sn_first[s]];
   }
 
-  // ---- relaxed amalgamation (nemin) -------------------------------------
-  // A node is merged into its parent when that creates no fill, or when both
-  // have fewer than nemin columns (the rule SSIDS applies for SpLLT,
-  // reference src/spllt_analyse_mod.F90:112-116).
+  // ---- relaxed amalgamation ------------------------------------------------
+  // A node is merged into its parent when
+  //   * that creates no fill, or
+  //   * both have fewer than nemin columns (the rule SSIDS applies for SpLLT,
+  //     reference src/spllt_analyse_mod.F90:112-116), or
+  //   * the explicit zeros the merge introduces stay a small fraction of the
+  //     merged trapezoid (separators produced by nested dissection split into
+  //     chains of supernodes whose row structures differ by a few rows; gluing
+  //     them back costs a few per cent of storage and removes most of the
+  //     sequential panel steps of the factorization).
   const int nemin = opt.nemin < 1 ? 32 : opt.nemin;
   std::vector<int> rep(ns);
   std::iota(rep.begin(), rep.end(), 0);
+  std::vector<int64_t> sm0(sm);            // original row counts
+  std::vector<double> nz_true(ns);         // structural nonzeros held by the (merged) node
+  for (int s = 0; s < ns; ++s) nz_true[s] = (double)sncol[s] * sm[s] - 0.5 * sncol[s] * (sncol[s] - 1);
   for (int s = 0; s < ns; ++s) {  // supernodes are already in postorder
     int p = sp[s];
     if (p < 0) continue;
-    bool exact = (sm[s] - sncol[s] == sm[p]);
-    bool tiny = (sncol[s] < nemin && sncol[p] < nemin);
-    if (exact || tiny) {
+    const bool exact = (sm[s] - sncol[s] == sm0[p]) && sncol[p] == (sn_first[p + 1] - sn_first[p]);
+    const bool tiny = (sncol[s] < nemin && sncol[p] < nemin);
+    // merged trapezoid: columns of both, rows = own columns + rows below the parent
+    const int64_t below = sm[p] - sncol[p];
+    const int64_t nc = sncol[p] + sncol[s];
+    const double nz_merged = (double)nc * (nc + below) - 0.5 * nc * (nc - 1);
+    const double zeros = nz_merged - (nz_true[s] + nz_true[p]);
+    const bool relaxed = opt.relax > 0.0 && zeros <= opt.relax * nz_merged && sm[s] - sncol[s] <= nc - sncol[s] + below;
+    if (exact || tiny || relaxed) {
       rep[s] = p;
-      int64_t below = sm[p] - sncol[p];
-      sncol[p] += sncol[s];
-      sm[p] = sncol[p] + below;
+      sncol[p] = nc;
+      sm[p] = nc + below;
+      nz_true[p] += nz_true[s];
     }
   }
   auto findrep = [&](int s) {
-    while (rep[s] != s) s = rep[s];
-    return s;
+    int r = s;
+    while (rep[r] != r) r = rep[r];
+    while (rep[s] != r) {  // path compression
+      int nx = rep[s];
+      rep[s] = r;
+      s = nx;
+    }
+    return r;
   };
   // final nodes, their tree, and a postorder of it
   std::vector<int> fin_id(ns, -1);
@@ -442,7 +463,6 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
       std::sort(tmp.begin(), tmp.end());
       below[s] = tmp;
       S.rptr[s + 1] = S.rptr[s] + (c1 - c0) + (int64_t)tmp.size();
-      S.rlist.reserve(S.rptr[s + 1]);
       for (int j = c0; j < c1; ++j) S.rlist.push_back(j);
       S.rlist.insert(S.rlist.end(), tmp.begin(), tmp.end());
     }

@@ -28,6 +28,7 @@ struct SymOptions {
   bool prune_tree = true;  // spllt_options%prune_tree
   int ncpu = 1;            // pruning target (number of workers / GPUs)
   int nd_leaf = 32;        // nested-dissection leaf size (built-in ordering)
+  double relax = 0.05;     // relaxed amalgamation: merge while explicit zeros <= relax * entries
 };
 
 // One block column of L: a row-major (nrow x width) matrix, rows r0..m-1 of
