@@ -173,6 +173,19 @@ def main():
                  "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
 
     roof, table, ms = roofline_from_profile(f, val)
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc
+    # passes (scripts/gpu_pmc.sh; FETCH_SIZE/WRITE_SIZE cannot be read from
+    # inside this process); the committed summary is quoted when it was taken
+    # on this very workload.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("workload") == name:
+            roof["traffic"] = round(pmc["hbm_bytes_per_launch"])
+            roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_summary.json)"
+            roof["algorithmic_bytes_per_launch"] = round(pmc["algorithmic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
     if args.profile_out:
         Lh = f.program("launches")
         with open(args.profile_out, "w") as fh:

@@ -37,6 +37,9 @@ CASES = [
     ("box12-nb256", lambda: matgen.nd_like((12, 12, 11), 3), 256, 32, None),
     ("fe27-nb64", lambda: matgen.fe27((5, 5, 4), 3), 64, 16, None),
     ("p2d128-nb256", lambda: matgen.poisson2d(128), 256, 32, None),  # BASELINE config 1
+    ("p3d20-nb384", lambda: matgen.poisson3d(20), 384, 32, None),    # config 3 tile size
+    ("fe27-nb512", lambda: matgen.fe27((9, 8, 8), 3), 512, 32, None),   # config 4 tile size / pattern
+    ("fe27-nb768", lambda: matgen.fe27((10, 9, 9), 3), 768, 32, None),  # config 5 tile size / pattern
 ]
 
 
