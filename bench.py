@@ -165,9 +165,13 @@ def main():
     t_d2h = time.perf_counter() - t0
 
     check = {}
+    t_solve = None
     if not args.no_check:
         b = A @ np.ones(n)
+        f.solve(b)  # builds the device solve tables
+        t0 = time.perf_counter()
         x = f.solve(b)
+        t_solve = time.perf_counter() - t0
         r = b - A @ x
         check = {"resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
                  "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
@@ -214,6 +218,7 @@ def main():
         "roofline": roof, "cpu_baseline": cpu,
         "detail": {"device_ms_per_step": round(float(np.mean(dev_ms)), 3), "analyse_s": round(t_analyse, 2),
                    "dropin_factor_s": round(t_h2d, 4), "L_d2h_s": round(t_d2h, 4),
+                   "device_solve_s": None if t_solve is None else round(t_solve, 5),
                    "launches": f.times()["launches"], "kernel_table": table, "check": check},
     }
     print(json.dumps(out))

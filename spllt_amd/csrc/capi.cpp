@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -293,9 +294,20 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
     if (info) info->flag = SPLLT_ERROR_PARAMETER;
     return;
   }
-  int rc = ensure_hostL(f);
+  // Solve on the device-resident factor (no D2H of L).  SPLLT_HIP_HOST_SOLVE=1
+  // selects the host substitution instead (debugging aid).
+  int rc = do_wait(f);
+  if (rc == 0 && !f->eng) rc = SPLLT_ERROR_PARAMETER;  // nothing factorized yet
   if (rc) { if (info) info->flag = rc; return; }
-  host_solve(*f->S, f->hostL.data(), nrhs, x, job);
+  static const bool host_solve_env = std::getenv("SPLLT_HIP_HOST_SOLVE") != nullptr;
+  if (host_solve_env || f->eo.nranks > 1) {
+    rc = ensure_hostL(f);
+    if (rc) { if (info) info->flag = rc; return; }
+    host_solve(*f->S, f->hostL.data(), nrhs, x, job);
+  } else {
+    rc = f->eng->solve(x, nrhs, job);
+    if (rc) { if (info) info->flag = rc; return; }
+  }
   fill_info(*f->S, info);
 }
 

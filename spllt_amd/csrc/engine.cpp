@@ -154,6 +154,7 @@ Engine::~Engine() {
   if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
   hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_);
+  hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
   if (ev0_) hipEventDestroy(ev0_);
@@ -313,6 +314,40 @@ int Engine::download(double* out, int64_t count) {
   if (count > S_->arena) count = S_->arena;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipMemcpy(out, d_L_, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost), "L D2H");
+  return 0;
+}
+
+int Engine::solve(double* x_host, int nrhs, int job) {
+  if (status_) return status_;
+  if (job < 0 || job > 2) return -10;
+  const Symbolic& S = *S_;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  if (!solve_ready_) {
+    build_solve_program(S, prog_.pw, sprog_);
+    HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
+    HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
+    HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");
+    HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * (size_t)std::max(1, S.n)), "hipMalloc(y)");
+    solve_ready_ = true;
+  }
+  const int n = S.n;
+  std::vector<double> yh((size_t)n);
+  for (int r = 0; r < nrhs; ++r) {
+    double* xr = x_host + (int64_t)r * n;
+    for (int i = 0; i < n; ++i) yh[S.order[i]] = xr[i];
+    HIPCHK(hipMemcpyAsync(d_y_, yh.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream_), "rhs H2D");
+    auto run = [&](const std::vector<SolveLaunch>& ls) {
+      for (const SolveLaunch& l : ls)
+        launch_solve(stream_, l.kind, d_slist_, d_stiles_, l.first, l.count, d_sunits_, d_L_, d_dinv_,
+                     d_rlist_, d_y_);
+    };
+    if (job == 0 || job == 1) run(sprog_.fwd);
+    if (job == 0 || job == 2) run(sprog_.bwd);
+    HIPCHK(hipGetLastError(), "solve launch");
+    HIPCHK(hipMemcpyAsync(yh.data(), d_y_, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream_), "x D2H");
+    HIPCHK(hipStreamSynchronize(stream_), "solve sync");
+    for (int i = 0; i < n; ++i) xr[i] = yh[S.order[i]];
+  }
   return 0;
 }
 

@@ -63,6 +63,9 @@ class Engine {
   int not_posdef_column() const { return npd_col_; }
 
   int download(double* out, int64_t count);  // D2H of the arena
+  // spllt_solve on the device-resident factor (x: n x nrhs column-major, original
+  // variable order, overwritten).  job 0 = both sweeps, 1 = forward, 2 = backward.
+  int solve(double* x_host, int nrhs, int job);
   double* device_L() { return d_L_; }
   hipStream_t stream() { return stream_; }
   const Program& program() const { return prog_; }
@@ -114,6 +117,13 @@ class Engine {
   UpdTile* d_tiles_ = nullptr;
   PotrfUnit* d_potrf_ = nullptr;
   StripUnit* d_strips_ = nullptr;
+  // device solve (built on first use)
+  SolveProgram sprog_;
+  bool solve_ready_ = false;
+  SolveUnit* d_sunits_ = nullptr;
+  int* d_slist_ = nullptr;
+  UpdTile* d_stiles_ = nullptr;
+  double* d_y_ = nullptr;
   int* d_relpos_ = nullptr;
   int* d_rlist_ = nullptr;
   int* d_flag_ = nullptr;

@@ -644,6 +644,151 @@ __global__ __launch_bounds__(256) void k_expand_buffer(double* __restrict__ a, i
 }
 
 // ---------------------------------------------------------------------------
+// Triangular solves with the device-resident factor (reference solve_fwd /
+// solve_bwd, src/spllt_solve_mod.F90:244-411; per-block kernels
+// src/spllt_solve_kernels_mod.F90:11-210).  y is the right-hand side in pivot
+// order, overwritten by the solution.  HBM-bound: every entry of L is read once
+// per sweep, row-major rows are read by 16 or 64 consecutive lanes.
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Solve with the diagonal tile of one block column per workgroup, using the
+// inverted 64x64 diagonal panels:  forward  x_p = inv(L_pp) (y_p - L_p,<p x_<p),
+// backward x_p = inv(L_pp)^T (y_p - L_>p,p^T x_>p).
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list,
+                                                    const SolveUnit* __restrict__ units,
+                                                    const double* __restrict__ L,
+                                                    const double* __restrict__ dinv,
+                                                    const int* __restrict__ rlist,
+                                                    double* __restrict__ y) {
+  __shared__ double xb[1024];
+  __shared__ double tb[64];
+  __shared__ double part[4][64];
+  const SolveUnit u = units[list[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = u.w, pw = u.pw;
+  const double* A = L + u.off;
+  const int* idx = rlist + u.idx_off;
+  for (int j = tid; j < w; j += 256) xb[j] = y[idx[j]];
+  __syncthreads();
+  const int np = (w + pw - 1) / pw;
+  for (int pp = 0; pp < np; ++pp) {
+    const int p = BWD ? np - 1 - pp : pp;
+    const int c0 = p * pw, pn = min(pw, w - c0);
+    int64_t slot = u.dinv_off + (int64_t)p * pw * pw;  // panels before p are full width
+    const double* D = dinv + slot;
+    if (!BWD) {
+      // t_j = y_j - sum_{k<c0} L[c0+j][k] x_k : one wave per row, lanes over k
+      for (int j = wave; j < pn; j += 4) {
+        const double* row = A + (int64_t)(c0 + j) * w;
+        double sacc = 0.0;
+        for (int k = lane; k < c0; k += 64) sacc += row[k] * xb[k];
+        sacc = wave_sum(sacc);
+        if (lane == 0) tb[j] = xb[c0 + j] - sacc;
+      }
+      __syncthreads();
+      // x_j = sum_{k<=j} Dinv[j][k] t_k
+      for (int j = wave; j < pn; j += 4) {
+        double sacc = (lane <= j && lane < pn) ? D[j * pn + lane] * tb[lane] : 0.0;
+        sacc = wave_sum(sacc);
+        if (lane == 0) xb[c0 + j] = sacc;
+      }
+      __syncthreads();
+    } else {
+      // t_j = y_j - sum_{k>=c0+pn} L[k][c0+j] x_k : lane = column j, waves split k
+      {
+        double sacc = 0.0;
+        if (lane < pn)
+          for (int k = c0 + pn + wave; k < w; k += 4) sacc += A[(int64_t)k * w + c0 + lane] * xb[k];
+        part[wave][lane] = sacc;
+      }
+      __syncthreads();
+      if (tid < pn) tb[tid] = xb[c0 + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+      __syncthreads();
+      // x_j = sum_{k>=j} Dinv[k][j] t_k
+      {
+        double sacc = 0.0;
+        if (lane < pn)
+          for (int k = lane + wave; k < pn; k += 4) sacc += D[k * pn + lane] * tb[k];
+        part[wave][lane] = sacc;
+      }
+      __syncthreads();
+      if (tid < pn) xb[c0 + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+      __syncthreads();
+    }
+  }
+  for (int j = tid; j < w; j += 256) y[idx[j]] = xb[j];
+}
+
+// Rows below the diagonal tile, one strip of kSolveStripRows rows per workgroup.
+//   forward : y[idx[r]] -= sum_k L[r][k] x_k      (x = solved entries of this block column)
+//   backward: y[idx[k]] -= sum_r L[r][k] x[idx[r]]
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__ tiles,
+                                                     const SolveUnit* __restrict__ units,
+                                                     const double* __restrict__ L,
+                                                     const int* __restrict__ rlist,
+                                                     double* __restrict__ y) {
+  __shared__ double xb[1024];
+  const UpdTile tl = tiles[blockIdx.x];
+  const SolveUnit u = units[tl.unit];
+  const int tid = threadIdx.x;
+  const int w = u.w;
+  const int r0 = w + (int)tl.ti * kSolveStripRows;
+  const int nr = min(kSolveStripRows, u.nrow - r0);
+  const double* A = L + u.off + (int64_t)r0 * w;
+  const int* idx = rlist + u.idx_off;
+  if (!BWD) {
+    for (int k = tid; k < w; k += 256) xb[k] = y[idx[k]];
+    __syncthreads();
+    // 16 lanes per row: coalesced 128-byte reads, 4-step reduction
+    const int sub = tid & 15, rr = tid >> 4;  // 16 rows per pass
+    for (int r = rr; r < nr; r += 16) {
+      const double* row = A + (int64_t)r * w;
+      double sacc = 0.0;
+      for (int k = sub; k < w; k += 16) sacc += row[k] * xb[k];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
+      if (sub == 0) unsafeAtomicAdd(y + idx[r0 + r], -sacc);
+    }
+  } else {
+    for (int r = tid; r < nr; r += 256) xb[r] = y[idx[r0 + r]];
+    __syncthreads();
+    for (int k = tid; k < w; k += 256) {
+      double sacc = 0.0;
+      for (int r = 0; r < nr; ++r) sacc += A[(int64_t)r * w + k] * xb[r];
+      unsafeAtomicAdd(y + idx[k], -sacc);
+    }
+  }
+}
+
+void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
+                  int64_t count, const SolveUnit* units, const double* L, const double* dinv,
+                  const int* rlist, double* y) {
+  if (count <= 0) return;
+  const dim3 g((unsigned)count), b(256);
+  switch (kind) {
+    case SV_DIAG_FWD:
+      hipLaunchKernelGGL(k_solve_diag<false>, g, b, 0, st, list + first, units, L, dinv, rlist, y);
+      break;
+    case SV_DIAG_BWD:
+      hipLaunchKernelGGL(k_solve_diag<true>, g, b, 0, st, list + first, units, L, dinv, rlist, y);
+      break;
+    case SV_STRIP_FWD:
+      hipLaunchKernelGGL(k_solve_strip<false>, g, b, 0, st, tiles + first, units, L, rlist, y);
+      break;
+    default:
+      hipLaunchKernelGGL(k_solve_strip<true>, g, b, 0, st, tiles + first, units, L, rlist, y);
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // launch wrappers (plain C++ callers do not see HIP launch syntax)
 // ---------------------------------------------------------------------------
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,

@@ -24,6 +24,10 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
 // rs = rows per strip: 32 (block column width <= 320) or 16 (<= 896)
 void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
                   const StripUnit* units, double* L, const double* dinv);
+// one launch of the device solve (kind = SolveKind)
+void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
+                  int64_t count, const SolveUnit* units, const double* L, const double* dinv,
+                  const int* rlist, double* y);
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
                           const int* col_list, int cls, int ndiag, const double* buffer);
 

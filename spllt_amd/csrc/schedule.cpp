@@ -547,4 +547,73 @@ void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {
   b.run();
 }
 
+void build_solve_program(const Symbolic& S, int pw, SolveProgram& P) {
+  P = SolveProgram();
+  pw = std::min(pw, kPanelMax);
+  const int nn = S.nnodes, nbc = S.nbcol();
+  P.units.resize(nbc);
+  {
+    int64_t o = 0;
+    for (int b = 0; b < nbc; ++b) {
+      const BlockCol& B = S.bcols[b];
+      SolveUnit& u = P.units[b];
+      u.off = B.off;
+      u.dinv_off = o;
+      u.idx_off = S.rptr[B.node] + B.r0;
+      u.w = B.width;
+      u.nrow = B.nrow;
+      u.pw = pw;
+      u.pad_ = 0;
+      for (int c = 0; c < B.width; c += pw) {
+        int pn = std::min(pw, B.width - c);
+        o += (int64_t)pn * pn;
+      }
+    }
+  }
+  int maxlevel = -1;
+  for (int s = 0; s < nn; ++s) maxlevel = std::max(maxlevel, S.level[s]);
+  std::vector<std::vector<int>> by_level(maxlevel + 1);
+  for (int s = 0; s < nn; ++s) by_level[S.level[s]].push_back(s);
+  // one (diag, strip) launch pair per level and block-column step; the same
+  // pairs are replayed in reverse for the backward substitution
+  struct Step { int level; int64_t d0, dn, t0, tn; };
+  std::vector<Step> steps;
+  for (int lev = 0; lev <= maxlevel; ++lev) {
+    const auto& nodes = by_level[lev];
+    int maxnc = 0;
+    for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
+    for (int c = 0; c < maxnc; ++c) {
+      Step st;
+      st.level = lev;
+      st.d0 = (int64_t)P.diag_list.size();
+      st.t0 = (int64_t)P.tiles.size();
+      for (int s : nodes) {
+        int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+        if (c >= nc) continue;
+        int b = S.node_bcol0[s] + c;
+        P.diag_list.push_back(b);
+        int below = S.bcols[b].nrow - S.bcols[b].width;
+        for (int t = 0; t * kSolveStripRows < below; ++t) {
+          UpdTile tt;
+          tt.unit = b;
+          tt.ti = (short)t;
+          tt.tj = 0;
+          P.tiles.push_back(tt);
+        }
+      }
+      st.dn = (int64_t)P.diag_list.size() - st.d0;
+      st.tn = (int64_t)P.tiles.size() - st.t0;
+      steps.push_back(st);
+    }
+  }
+  for (const Step& st : steps) {
+    if (st.dn > 0) P.fwd.push_back(SolveLaunch{SV_DIAG_FWD, st.level, st.d0, st.dn});
+    if (st.tn > 0) P.fwd.push_back(SolveLaunch{SV_STRIP_FWD, st.level, st.t0, st.tn});
+  }
+  for (auto it = steps.rbegin(); it != steps.rend(); ++it) {
+    if (it->tn > 0) P.bwd.push_back(SolveLaunch{SV_STRIP_BWD, it->level, it->t0, it->tn});
+    if (it->dn > 0) P.bwd.push_back(SolveLaunch{SV_DIAG_BWD, it->level, it->d0, it->dn});
+  }
+}
+
 }  // namespace spx

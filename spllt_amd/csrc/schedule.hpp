@@ -125,4 +125,41 @@ struct ScheduleOptions {
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);
 
+// ---------------------------------------------------------------------------
+// Triangular solves with the device-resident factor (SURVEY.md 8(f) row f2;
+// reference solve_fwd / solve_bwd, src/spllt_solve_mod.F90:244-411).  The same
+// level batching as the factorization: per level and block-column step one
+// "diag" launch (solve with the diagonal tile through the inverted 64x64
+// panels the factorization left in the dinv scratch) and one "strip" launch
+// (rows below: forward  y[rows] -= L_strip x,  backward  y[cols] -= L_strip^T x[rows]).
+// ---------------------------------------------------------------------------
+struct SolveUnit {
+  int64_t off;       // arena offset of the block column
+  int64_t dinv_off;  // dinv slot of its panel 0
+  int64_t idx_off;   // offset into rlist[] of the block column's first row (= its first column)
+  int w;             // width
+  int nrow;          // rows stored (w diagonal rows + rows below)
+  int pw;            // panel width
+  int pad_;
+};
+
+enum SolveKind : int { SV_DIAG_FWD = 0, SV_STRIP_FWD = 1, SV_STRIP_BWD = 2, SV_DIAG_BWD = 3 };
+
+struct SolveLaunch {
+  int kind;
+  int level;
+  int64_t first, count;  // DIAG: range in units; STRIP: range in tiles (unit, strip)
+};
+
+constexpr int kSolveStripRows = 256;
+
+struct SolveProgram {
+  std::vector<SolveUnit> units;   // one per block column, indexed by block column id
+  std::vector<int> diag_list;     // unit ids in launch order (DIAG launches index this)
+  std::vector<UpdTile> tiles;     // (unit, strip) pairs in launch order
+  std::vector<SolveLaunch> fwd, bwd;
+};
+
+void build_solve_program(const Symbolic& S, int pw, SolveProgram& P);
+
 }  // namespace spx
