@@ -95,7 +95,8 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
 /* engine knobs (before the first spllt_factor on this fkeep); flags: bit 0 =
  * replay through a hipGraph, bit 1 = single-stream program (no lookahead),
  * bit 2 = fused strip-TRSM kernel + tile-level lookahead on latency-bound levels
- * (measured slower than the default on MI355X, kept for experiments) */
+ * (experiment), bit 3 = with bit 2: keep per-panel launches for the diagonal tile
+ * instead of the single-workgroup tile-chain kernel */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------

@@ -2,7 +2,7 @@
 # A/B of engine variants on the bench workload (one process per variant; quick)
 OUT=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out
 mkdir -p $OUT
-run() { # name, env..., flags
+run() { # name, env...
   name=$1; shift
   env "$@" timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check > $OUT/var_$name.json 2> $OUT/var_$name.err
   python - <<PY
@@ -13,9 +13,7 @@ except Exception as e:
     print("$name FAILED", e)
 PY
 }
-run fused_default SPLLT_ENGINE_FLAGS=0
-run unfused SPLLT_ENGINE_FLAGS=4
-run unfused_res16 SPLLT_ENGINE_FLAGS=4 SPLLT_HIP_RESERVE_CUS=16
-run fused_res16 SPLLT_ENGINE_FLAGS=0 SPLLT_HIP_RESERVE_CUS=16
-run fused_res32 SPLLT_ENGINE_FLAGS=0 SPLLT_HIP_RESERVE_CUS=32
+run default SPLLT_ENGINE_FLAGS=0
+run chain_strip SPLLT_ENGINE_FLAGS=4
+run strip_only SPLLT_ENGINE_FLAGS=12
 run single_stream SPLLT_ENGINE_FLAGS=2

@@ -126,7 +126,7 @@ class Factorization:
             return raw.view(UPD_UNIT_DTYPE)
         if name == "tiles":
             return raw.view(UPD_TILE_DTYPE)
-        if name == "potrf":
+        if name in ("potrf", "chains"):
             return raw.view(POTRF_UNIT_DTYPE)
         if name == "relpos":
             return raw.view(np.int32)

@@ -465,6 +465,7 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) 
   f->eo.use_graph = (use_graph & 1) != 0;
   f->eo.lookahead = (use_graph & 2) == 0;  // bit 1 set: single-stream program
   f->eo.fused_strip = (use_graph & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
+  f->eo.tile_chain = (use_graph & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
   return 0;
 }
 
@@ -581,6 +582,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.tile = f->eo.tile;
     so.lookahead = f->eo.lookahead;
     so.fused_strip = f->eo.fused_strip;
+    so.tile_chain = f->eo.tile_chain;
     std::vector<int> owner;
     if (f->eo.nranks > 1) {
       assign_owners(*f->S, f->eo.nranks, owner);
@@ -610,6 +612,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
   if (k == "strips") return raw(P->strip_units.data(), P->strip_units.size() * sizeof(StripUnit));
+  if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(PotrfUnit));
   if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
   return -1;
 }

@@ -58,6 +58,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
   so.fused_strip = opt_.fused_strip;
+  so.tile_chain = opt_.tile_chain;
   if (opt_.nranks > 1) {
     assign_owners(*S_, opt_.nranks, owner_);
     so.node_owner = owner_.data();
@@ -138,6 +139,7 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
   HIPCHK(dev_upload(&d_potrf_, prog_.potrf_units), "upload potrf units");
   HIPCHK(dev_upload(&d_strips_, prog_.strip_units), "upload strip units");
+  HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
@@ -153,7 +155,7 @@ Engine::~Engine() {
   if (graph_exec_) hipGraphExecDestroy(graph_exec_);
   if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_); hipFree(d_chain_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
@@ -174,6 +176,8 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     else if (l.kind == L_STRIP)
       launch_strip(st, l.tile, d_tiles_ + l.first, l.count, d_strips_, d_L_, d_dinv_);
+    else if (l.kind == L_CHAIN)
+      launch_tile_chain(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     else
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
                     d_relpos_, d_rlist_, d_dinv_);

@@ -21,6 +21,7 @@ struct EngineOptions {
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
   bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
+  bool tile_chain = true;   // (with fused_strip) single-workgroup panel chain per diagonal tile
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
 };
 
@@ -117,6 +118,7 @@ class Engine {
   UpdTile* d_tiles_ = nullptr;
   PotrfUnit* d_potrf_ = nullptr;
   StripUnit* d_strips_ = nullptr;
+  PotrfUnit* d_chain_ = nullptr;
   // device solve (built on first use)
   SolveProgram sprog_;
   bool solve_ready_ = false;

@@ -104,18 +104,25 @@ __device__ unsigned long long g_potrf_stamps[32];
 #define STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
-                                                     double* __restrict__ L,
-                                                     double* __restrict__ dinv,
-                                                     int* __restrict__ flag) {
-  __shared__ double T[64 * TLD];
-  __shared__ double X[64 * TLD];
-  __shared__ double DI[4][16 * DLD];
-  __shared__ double RI[64];  // reciprocals of the diagonal of L
-  const PotrfUnit u = units[blockIdx.x];
-  const int n = u.n, ld = u.ld, tid = threadIdx.x;
+struct PotrfShared {
+  double T[64 * TLD];
+  double X[64 * TLD];
+  double DI[4][16 * DLD];
+  double RI[64];  // reciprocals of the diagonal of L
+};
+
+// Factor (and invert) one <=64 x <=64 block held at A (row stride ld); the whole
+// workgroup takes part.  D receives inv(L) (row-major, ld = n).
+__device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict__ A, int ld, int n,
+                                             double* __restrict__ D, int gcol, int flags,
+                                             int* __restrict__ flag) {
+  double (&T)[64 * TLD] = sh.T;
+  double (&X)[64 * TLD] = sh.X;
+  double (&DI)[4][16 * DLD] = sh.DI;
+  double (&RI)[64] = sh.RI;
+  struct { int n, ld, gcol, flags; } u = {n, ld, gcol, flags};
+  const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  double* A = L + u.off;
   const int nblk = (n + 15) >> 4;
   const int np = nblk * 16;
   const bool do_chol = !(u.flags & 1);
@@ -263,7 +270,6 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
     __syncthreads();
   }
   STAMP(15);
-  double* D = dinv + u.dinv_off;
   if (li < n) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -275,6 +281,124 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
     }
   }
   STAMP(16);
+}
+
+__global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
+                                                     double* __restrict__ L,
+                                                     double* __restrict__ dinv,
+                                                     int* __restrict__ flag) {
+  __shared__ PotrfShared sh;
+  const PotrfUnit u = units[blockIdx.x];
+  potrf64_body(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.gcol, u.flags, flag);
+}
+
+// ---------------------------------------------------------------------------
+// The whole panel chain of one diagonal tile (w <= 256) in ONE workgroup:
+//   for every 64-wide panel p:  update the panel's block column inside the tile
+//   by the previous panels, factor + invert its diagonal block, solve the
+//   tile rows below it.
+// It replaces 3*np-1 dependent launches on the critical path (each of which has
+// to win CU slots against the concurrently running trailing update) by a single
+// resident workgroup.  The tile-local products read their MFMA operands
+// straight from global memory (the tile is 512 KB and L2-resident).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_chain(const PotrfUnit* __restrict__ units,
+                                                    double* __restrict__ L,
+                                                    double* __restrict__ dinv,
+                                                    int* __restrict__ flag) {
+  __shared__ PotrfShared sh;
+  const PotrfUnit u = units[blockIdx.x];   // off = block column, n = tile order, flags = panel width
+  const int w = u.ld, nt = u.n, pw = u.flags;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  double* A = L + u.off;
+  int64_t slot = u.dinv_off;
+  for (int c0 = 0; c0 < nt; c0 += pw) {
+    const int pn = min(pw, nt - c0);
+    const int nct = (pn + 15) >> 4;
+    if (c0 > 0) {
+      // (a) A[r][c0+j] -= sum_{k<c0} A[r][k] A[c0+j][k],  r in [c0, nt), lower part
+      const int nrt = (nt - c0 + 15) >> 4;
+      for (int t = wave; t < nrt * nct; t += 4) {
+        const int rt = t / nct, ct = t - rt * nct;
+        if (rt < ct) continue;  // entirely above the diagonal
+        const int rbase = c0 + rt * 16, cbase = c0 + ct * 16;
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + lq + 4 * r, col = cbase + lr;
+          acc[r] = (row < nt && col < c0 + pn) ? A[(int64_t)row * w + col] : 0.0;
+        }
+        const int ra = min(rbase + lr, nt - 1), rb = min(cbase + lr, nt - 1);
+        const double* pa = A + (int64_t)ra * w + lq;
+        const double* pb = A + (int64_t)rb * w + lq;
+        // c0 is a multiple of the panel width (64): 16 k-steps per chunk, all 32
+        // operand loads of a chunk in flight before its MFMAs
+        for (int k0 = 0; k0 < c0; k0 += 64) {
+          double av[16], bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int k = k0 + 4 * t;
+            av[t] = k < c0 ? pa[k] : 0.0;
+            bv[t] = k < c0 ? pb[k] : 0.0;
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[t], bv[t], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + lq + 4 * r, col = cbase + lr;
+          if (row < nt && col < c0 + pn && row >= col) A[(int64_t)row * w + col] = acc[r];
+        }
+      }
+      __syncthreads();
+    }
+    // (b) factor + invert the diagonal block of the panel
+    potrf64_body(sh, A + (int64_t)c0 * w + c0, w, pn, dinv + slot, u.gcol + c0, 0, flag);
+    __syncthreads();
+    // (c) rows below the panel inside the tile: X = A * inv(L_pp)^T, one 16-row
+    // tile per wave (its K operand is loaded completely before it is overwritten)
+    {
+      const double* D = dinv + slot;
+      const int r1 = c0 + pn;
+      const int nrt = (nt - r1 + 15) >> 4;
+      const int ksteps = (pn + 3) >> 2;
+      for (int rt = wave; rt < nrt; rt += 4) {
+        const int rbase = r1 + rt * 16;
+        const int ra = min(rbase + lr, nt - 1);
+        double av[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int k = 4 * t + lq;
+          const double v = A[(int64_t)ra * w + c0 + min(k, pn - 1)];
+          av[t] = (t < ksteps && k < pn && rbase + lr < nt) ? v : 0.0;
+        }
+        for (int ct = 0; ct < nct; ++ct) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+          const int jrow = min(ct * 16 + lr, pn - 1);
+          double bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int k = min(4 * t + lq, pn - 1);
+            bv[t] = D[jrow * pn + k];
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int k = 4 * t + lq;
+            const double b = (t < ksteps && k < pn && ct * 16 + lr < pn) ? bv[t] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rbase + lq + 4 * r, col = ct * 16 + lr;
+            if (row < nt && col < pn) A[(int64_t)row * w + c0 + col] = acc[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    slot += (int64_t)pn * pn;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -812,6 +936,12 @@ void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double*
                   int* flag) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+}
+
+void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, double* L,
+                       double* dinv, int* flag) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_tile_chain, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
 }
 
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,

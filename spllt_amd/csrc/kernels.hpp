@@ -13,6 +13,10 @@ void launch_scatter_val(hipStream_t st, double* L, const double* val, const int6
                         const int64_t* src, int64_t n);
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag);
+// whole panel chain of one diagonal tile per workgroup (unit: off = block column,
+// ld = width, n = tile order (<= 256), flags = panel width)
+void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, double* L,
+                       double* dinv, int* flag);
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv);

@@ -211,7 +211,48 @@ struct Builder {
         auto chain_rows = [&](const BlockCol& B) {
           return (fs && B.width <= 896) ? std::min(B.nrow, B.width) : B.nrow;
         };
-        for (int p = 0; p < maxp; ++p) {
+        // (0) single-workgroup panel chain of the diagonal tiles (fused mode, w <= 256)
+        bool chained = false;
+        if (fs && opt.tile_chain) {
+          bool all_fit = true;
+          for (int s : nodes) {
+            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c < nc && S.bcols[S.node_bcol0[s] + c].width > 256) all_fit = false;
+          }
+          if (all_fit) {
+            Launch L;
+            L.kind = L_CHAIN;
+            L.level = lev;
+            L.first = (int64_t)P.chain_units.size();
+            L.tile = 0;
+            double fl = 0;
+            for (int s : nodes) {
+              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              PotrfUnit q{};
+              q.off = B.off;
+              q.dinv_off = dinv_slot[b];
+              q.ld = B.width;
+              q.n = std::min(B.nrow, B.width);
+              q.gcol = S.sptr[s] + B.r0;
+              q.flags = pw;
+              P.chain_units.push_back(q);
+              fl += (double)q.n * q.n * q.n / 3.0;
+            }
+            L.count = (int64_t)P.chain_units.size() - L.first;
+            L.flops = fl;
+            P.flops_potrf += fl;
+            if (first_of_level) {
+              L.wait0 = ev_level;
+              first_of_level = false;
+            }
+            if (L.count > 0) P.launches.push_back(L);
+            chained = true;
+          }
+        }
+        for (int p = 0; p < maxp && !chained; ++p) {
           // (1) left-looking update of panel p by the previous panels of the block column
           double fl = 0;
           if (p > 0) {

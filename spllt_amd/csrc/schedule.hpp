@@ -78,7 +78,7 @@ struct StripUnit {
   int pw;            // panel width
 };
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3 };
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3, L_CHAIN = 4 };
 
 struct Launch {
   int kind;
@@ -97,6 +97,7 @@ struct Launch {
 struct Program {
   int pw = 64;  // inner panel width
   std::vector<PotrfUnit> potrf_units;
+  std::vector<PotrfUnit> chain_units;  // L_CHAIN: off = block column, n = tile order, flags = panel width
   std::vector<UpdUnit> units;
   std::vector<UpdTile> tiles;
   std::vector<StripUnit> strip_units;  // L_STRIP launches: tiles[].unit indexes this, .ti = strip
@@ -121,6 +122,8 @@ struct ScheduleOptions {
                           // overlaps the trailing update by block column c
   bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
   int strip_limit = 512;    // ... on levels whose steps have at most this many strips
+  bool tile_chain = true;   // with fused_strip: the panel chain of a diagonal tile (w <= 256)
+                            // runs as ONE workgroup (k_tile_chain) instead of 3*np-1 launches
 };
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);

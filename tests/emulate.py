@@ -59,6 +59,21 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 arena[s_] = xbuf[o:o + k]
                 o += k
             continue
+        if kind == 4:  # single-workgroup panel chain = Cholesky of the diagonal tile + panel inverses
+            for q in f.program("chains")[first:first + count]:
+                w, nt, off, pwq = int(q["ld"]), int(q["n"]), int(q["off"]), int(q["flags"])
+                idx = off + np.arange(nt)[:, None] * w + np.arange(nt)[None, :]
+                blk = np.tril(arena[idx])
+                Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
+                low = np.tril_indices(nt)
+                arena[idx[low]] = Lb[low]
+                slot = int(q["dinv_off"])
+                for c0 in range(0, nt, pwq):
+                    pn = min(pwq, nt - c0)
+                    X = sl.solve_triangular(Lb[c0:c0 + pn, c0:c0 + pn], np.eye(pn), lower=True)
+                    dinv[slot:slot + pn * pn] = X.ravel()
+                    slot += pn * pn
+            continue
         if kind == 3:  # fused strip TRSM: rows below the diagonal tile, all panels
             strips = f.program("strips")
             rs = int(tile)

@@ -338,9 +338,10 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("flags", [2, 4])
+@pytest.mark.parametrize("flags", [2, 4, 12])
 def test_engine_variants_match_oracle(flags):
-    """single-stream program (2) and fused strip-TRSM + tile lookahead (4)."""
+    """single-stream program (2), fused strip-TRSM + tile lookahead with the
+    single-workgroup tile chain (4) and with per-panel launches (12)."""
     A = matgen.nd_like((12, 11, 10), 2)
     f, val = make_case(A, nb=64, nemin=16, panel_width=32, engine_flags=flags)
     got = f.factor(val).wait().get_factor()

@@ -146,6 +146,11 @@ def _access_sets(f):
                 W.add(2 * b)
                 R.add(2 * b)
                 W.add(2 * nbc + b)
+        elif kind == 4:
+            for q in f.program("chains")[first:first + count]:
+                b = int(np.searchsorted(off, q["off"], side="right") - 1)
+                W |= {2 * b, 2 * nbc + b}
+                R.add(2 * b)
         elif kind == 3:
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 q = strips[uid]
@@ -176,7 +181,7 @@ def _access_sets(f):
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
                                         (lambda: matgen.poisson3d(9), 24, 8)])
-@pytest.mark.parametrize("flags", [0, 4])
+@pytest.mark.parametrize("flags", [0, 4, 12])
 def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     """Two-stream lookahead program: any two launches that touch the same block
     column (write/write, read/write, atomic/plain) must be ordered by stream
@@ -186,7 +191,8 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     launches, acc = _access_sets(f)
     n = len(launches)
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
-    assert ((launches[:, 0] == 3).any()) == (flags == 4), "fused strip launches only with flag 4"
+    assert ((launches[:, 0] == 3).any()) == (flags in (4, 12)), "fused strip launches only with flag 4"
+    assert ((launches[:, 0] == 4).any()) == (flags == 4), "tile-chain launches with flag 4 (bit 3 disables)"
     rec_at = {}
     last_in_stream = {}
     before = [0] * n  # bitset of launches that happen-before launch i
@@ -225,13 +231,13 @@ def test_single_stream_program_has_no_events():
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
-@pytest.mark.parametrize("flags", [0, 4, 2, 6])
+@pytest.mark.parametrize("flags", [0, 4, 2, 6, 12])
 def test_program_variants_agree(flags):
     """fused strip / per-panel TRSM, two-stream / single-stream programs all
     reproduce the same factor (interpreted in numpy)."""
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
     L = f.program("launches")
-    assert ((L[:, 0] == 3).any()) == (flags == 4)   # strip kernel needs the two-stream program
+    assert ((L[:, 0] == 3).any()) == (flags in (4, 12))   # strip kernel needs the two-stream program
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
