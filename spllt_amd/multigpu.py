@@ -94,8 +94,17 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
     top_flops = flops - own_w.sum()
     check = {}
     if not args.no_check:
+      # step 1 (local, may fail on one rank only): fetch this rank's part of L;
+      # agree on success before entering the collective so that no rank hangs
+      L, ok = None, 1
       try:
         L = torch.tensor(df.f.get_factor(), dtype=torch.float64, device="cuda")
+      except Exception as e:
+        ok, check = 0, {"error": repr(e)[:200]}
+      okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+      dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+      if int(okt.item()) == 1:
+       try:
         # every rank holds its own subtrees + the whole top tree; non-owned
         # subtree block columns are zero, so a sum assembles L on every rank
         # once the (replicated) top tree is counted only from rank 0
@@ -113,7 +122,7 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
             check = {"resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
                      "bwd_err": float(np.linalg.norm(r) /
                                       (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
-      except Exception as e:  # the accuracy gate must never take the benchmark line down
+       except Exception as e:  # the accuracy gate must never take the benchmark line down
         check = {"error": repr(e)[:200]}
     out = None
     if rank == 0:
