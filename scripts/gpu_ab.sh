@@ -1,0 +1,14 @@
+#!/bin/bash
+# Generic A/B: each argument is "ENV=VAL ENV=VAL ..." applied to one bench.py run.
+OUT=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out
+mkdir -p $OUT
+i=0
+for cfg in "$@"; do
+  i=$((i+1))
+  env $cfg timeout -k 10 300 python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-check ${BENCH_ARGS} > $OUT/ab_$i.json 2> $OUT/ab_$i.err || { tail -3 $OUT/ab_$i.err; exit 1; }
+  python - "$cfg" $OUT/ab_$i.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+print("%-60s ms %.3f  GF %.0f  u128 %.1f TF" % (sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["achieved"]), flush=True)
+PY
+done

@@ -57,6 +57,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.pw = opt_.pw;
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
+  so.lazy_next = opt_.lazy_next;
   so.fused_strip = opt_.fused_strip;
   so.tile_chain = opt_.tile_chain;
   if (opt_.nranks > 1) {
@@ -85,6 +86,9 @@ int Engine::upload() {
   // Optional CU reservation (experiment knob SPLLT_HIP_RESERVE_CUS=n): the bulk
   // stream is masked off n CUs so that the latency-critical panel kernels
   // always find a free CU instead of queueing behind bulk workgroups.
+  if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
+  if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
+  if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);
   int reserve = 0;
   if (const char* e = std::getenv("SPLLT_HIP_RESERVE_CUS")) reserve = std::atoi(e);
   if (reserve > 0) {
@@ -178,9 +182,16 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       launch_strip(st, l.tile, d_tiles_ + l.first, l.count, d_strips_, d_L_, d_dinv_);
     else if (l.kind == L_CHAIN)
       launch_tile_chain(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
-    else
+    else {
+      // two-stream program: panel-chain launches run at raised wave priority and
+      // the trailing updates leave part of every CU free for them
+      const bool two = !serial && opt_.lookahead;
+      const int prio = (two && l.stream == 0) ? chain_prio_ : 0;
+      int pad = 0;
+      if (two && l.stream == 1) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
-                    d_relpos_, d_rlist_, d_dinv_);
+                    d_relpos_, d_rlist_, d_dinv_, prio, pad);
+    }
   }
   if (!serial && l.record >= 0) HIPCHK(hipEventRecord(dag_events_[l.record], st), "event record");
   return 0;

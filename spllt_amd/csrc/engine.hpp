@@ -20,6 +20,7 @@ struct EngineOptions {
   int tile = 128;
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
+  bool lazy_next = false;  // merge the c -> c+1 update into the panel updates of c+1
   bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
   bool tile_chain = true;   // (with fused_strip) single-workgroup panel chain per diagonal tile
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
@@ -91,6 +92,8 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr;       // panel stream (stream 0 of the program)
   hipStream_t bulk_ = nullptr;         // bulk stream (stream 1)
+  int chain_prio_ = 0;                 // s_setprio for panel-stream update launches
+  int bulk_pad128_ = 0, bulk_pad64_ = 0;  // dynamic-LDS padding of bulk-stream launches (bytes)
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
   hipGraph_t graph_ = nullptr;

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
                                                      double* __restrict__ dinv,
                                                      int* __restrict__ flag) {
   __shared__ PotrfShared sh;
+  __builtin_amdgcn_s_setprio(3);
   const PotrfUnit u = units[blockIdx.x];
   potrf64_body(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.gcol, u.flags, flag);
 }
@@ -402,26 +403,28 @@ __global__ __launch_bounds__(256) void k_tile_chain(const PotrfUnit* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// The update kernel.  One workgroup (256 threads = 2x2 waves) owns one T x T
-// tile of one unit; each wave owns a (T/2)x(T/2) quadrant = FM x FM MFMA
-// fragments.  K is streamed in steps of 16 through LDS ([row][k], row stride 18
+// The update kernel.  One workgroup (WM x WN waves) owns one T x T tile of one
+// unit; each wave owns a (T/WM)x(T/WN) block = FMM x FMN MFMA fragments.  K is streamed in steps of 16 through LDS ([row][k], row stride 18
 // doubles -> conflict-free ds_read_b64 for the MFMA operand pattern) with the
 // next step's global loads issued before the current step's MFMAs.
 // ---------------------------------------------------------------------------
-constexpr int BK = 16;
-constexpr int LDK = 18;
-
-template <int T>
-__global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ tiles,
+template <int T, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __restrict__ tiles,
                                                 const UpdUnit* __restrict__ units,
                                                 const int64_t* __restrict__ bc_off,
                                                 const int* __restrict__ bc_w,
                                                 double* __restrict__ L,
                                                 const int* __restrict__ relpos,
                                                 const int* __restrict__ rlist,
-                                                const double* __restrict__ dinv) {
-  constexpr int FM = T / 32;          // MFMA fragments per wave per dimension
-  constexpr int PER = T * BK / 256;   // doubles staged per thread per operand per step
+                                                const double* __restrict__ dinv, int prio) {
+  // latency-critical launches (panel chain) outrank the trailing-update waves
+  // they share a SIMD with
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  constexpr int LDK = BK + 2;         // 2*odd doubles: conflict-free ds_read_b64 (see above)
+  constexpr int NT = 64 * WM * WN;    // threads: WM x WN waves
+  constexpr int FMM = T / WM / 16;    // MFMA fragments per wave, rows
+  constexpr int FMN = T / WN / 16;    // MFMA fragments per wave, columns
+  constexpr int PER = T * BK / NT;    // doubles staged per thread per operand per step
   constexpr int TPR = BK / PER;       // threads per tile row
   __shared__ double As[T * LDK];
   __shared__ double Bs[T * LDK];
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
   const UpdTile tl = tiles[blockIdx.x];
   const UpdUnit u = units[tl.unit];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int i0 = tl.ti * T, j0 = tl.tj * T;
   const int M = u.M, N = u.N;
 
@@ -440,11 +443,11 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
   const int rowA = rowA_ok ? i0 + srow : M - 1;   // clamped: always a valid row
   const int rowB = rowB_ok ? j0 + srow : N - 1;
 
-  d4 acc[FM][FM];
+  d4 acc[FMM][FMN];
 #pragma unroll
-  for (int a = 0; a < FM; ++a)
+  for (int a = 0; a < FMM; ++a)
 #pragma unroll
-    for (int b = 0; b < FM; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < FMN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
 
   // ---- K-segment state -----------------------------------------------------
   int seg = 0, kk = 0, klen = 0;
@@ -531,16 +534,16 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
     // MFMAs of the staged step
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      double af[FM], bf[FM];
+      double af[FMM], bf[FMN];
       const int kq = ks * 4 + (lane >> 4);
 #pragma unroll
-      for (int a = 0; a < FM; ++a) af[a] = As[(wm * (T / 2) + a * 16 + (lane & 15)) * LDK + kq];
+      for (int a = 0; a < FMM; ++a) af[a] = As[(wm * (T / WM) + a * 16 + (lane & 15)) * LDK + kq];
 #pragma unroll
-      for (int b = 0; b < FM; ++b) bf[b] = Bs[(wn * (T / 2) + b * 16 + (lane & 15)) * LDK + kq];
+      for (int b = 0; b < FMN; ++b) bf[b] = Bs[(wn * (T / WN) + b * 16 + (lane & 15)) * LDK + kq];
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+      for (int a = 0; a < FMM; ++a)
 #pragma unroll
-        for (int b = 0; b < FM; ++b)
+        for (int b = 0; b < FMN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
@@ -550,22 +553,22 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
   if (u.mode == MODE_SCATTER) {
     // fused expand_buffer: dest[(relpos[i]-r0)*ld + (gcol[j]-c0)] -= acc
     double* D = L + u.d_off;
-    int dcol[FM];
+    int dcol[FMN];
 #pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      const int j = j0 + wn * (T / 2) + b * 16 + lc;
+    for (int b = 0; b < FMN; ++b) {
+      const int j = j0 + wn * (T / WN) + b * 16 + lc;
       dcol[b] = (j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
     }
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
+    for (int a = 0; a < FMM; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * (T / 2) + a * 16 + lr + 4 * r;
+        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
         if (i >= M) continue;
         const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          const int j = j0 + wn * (T / 2) + b * 16 + lc;
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
           if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
             unsafeAtomicAdd(D + drow + dcol[b], -acc[a][b][r]);
         }
@@ -574,20 +577,23 @@ __global__ __launch_bounds__(256, 2) void k_update(const UpdTile* __restrict__ t
     double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
     const bool trsm = (u.mode == MODE_TRSM);
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
+    for (int a = 0; a < FMM; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * (T / 2) + a * 16 + lr + 4 * r;
+        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
         if (i >= M) continue;
         double* drow = D + (int64_t)i * u.d_ld;
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          const int j = j0 + wn * (T / 2) + b * 16 + lc;
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
           if (j >= N) continue;
           if (trsm) {
             drow[j] = acc[a][b][r];
           } else if (!u.lower || u.src_r0 + i >= u.src_c0 + j) {
-            drow[j] -= acc[a][b][r];
+            // fire-and-forget L2 atomic: a read-modify-write through registers
+            // would serialise FM*4 global round trips per tile (the compiler
+            // cannot reorder the loads above the stores)
+            unsafeAtomicAdd(drow + j, -acc[a][b][r]);
           }
         }
       }
@@ -946,17 +952,29 @@ void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, do
 
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
-                   const int* relpos, const int* rlist, const double* dinv) {
+                   const int* relpos, const int* rlist, const double* dinv, int prio,
+                   int lds_pad) {
   if (count <= 0) return;
+  // lds_pad: extra (unused) dynamic LDS that caps the workgroups per CU of a
+  // trailing-update launch so that panel-chain kernels find room beside it
+  const unsigned pad = lds_pad > 0 ? (unsigned)lds_pad : 0u;
+  static const bool attr_once = [] {
+    (void)hipFuncSetAttribute((const void*)k_update<128, 16, 4, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_update<64, 16, 2, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    return true;
+  }();
+  (void)attr_once;
   if (tile == 128)
-    hipLaunchKernelGGL(k_update<128>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
-                       bc_off, bc_w, L, relpos, rlist, dinv);
+    hipLaunchKernelGGL((k_update<128, 16, 4, 2>), dim3((unsigned)count), dim3(512), pad, st, tiles,
+                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
   else if (tile == 64)
-    hipLaunchKernelGGL(k_update<64>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
-                       bc_off, bc_w, L, relpos, rlist, dinv);
+    hipLaunchKernelGGL((k_update<64, 16, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
+                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
   else
-    hipLaunchKernelGGL(k_update<32>, dim3((unsigned)count), dim3(256), 0, st, tiles, units,
-                       bc_off, bc_w, L, relpos, rlist, dinv);
+    hipLaunchKernelGGL((k_update<32, 32, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
+                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
 }
 
 void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,

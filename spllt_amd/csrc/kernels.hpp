@@ -19,7 +19,8 @@ void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, do
                        double* dinv, int* flag);
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
-                   const int* relpos, const int* rlist, const double* dinv);
+                   const int* relpos, const int* rlist, const double* dinv, int prio = 0,
+                   int lds_pad = 0);
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,
                           const int* csrc_index, const double* src, int lds,
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,

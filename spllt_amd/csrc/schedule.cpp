@@ -1,5 +1,6 @@
 // Host-side construction of the batched stream-DAG program (see schedule.hpp).
 #include "schedule.hpp"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdio>
@@ -10,6 +11,11 @@ namespace {
 struct Edge {
   int stream = 0, wait0 = -1, wait1 = -1, record = -1;
 };
+
+static int64_t env_int(const char* name, int64_t dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoll(v) : dflt;
+}
 
 struct Builder {
   const Symbolic& S;
@@ -70,8 +76,10 @@ struct Builder {
       if (pick_tile(u.M, u.N) == 128) n128 += (int64_t)cdiv(u.M, 128) * cdiv(u.N, 128);
       n64 += (int64_t)cdiv(u.M, 64) * cdiv(u.N, 64);
     }
-    const bool small_launch = n128 > 0 && n128 < 64;
-    const bool tiny_launch = n64 > 0 && n64 <= 192;
+    static const int64_t small_max = env_int("SPLLT_TILE_SMALL", 1024);
+    static const int64_t tiny_max = env_int("SPLLT_TILE_TINY", 2048);
+    const bool small_launch = n128 > 0 && n128 < small_max;
+    const bool tiny_launch = n64 > 0 && n64 <= tiny_max;
     for (auto& u : us) {
       int uid = (int)P.units.size();
       P.units.push_back(u);
@@ -90,6 +98,24 @@ struct Builder {
       } else {
         add_tiles(T == 128 ? t128 : (T == 64 ? t64 : t32), uid, u, T, low, 0, u.N);
       }
+    }
+    // longest tiles first: the K extent of a tile is its unit's source width, and a
+    // launch mixes units of very different K (inter-node updates), so dispatching
+    // the heavy tiles first shortens the tail of the launch
+    {
+      const int ubase = (int)P.units.size() - (int)us.size();
+      std::vector<int64_t> work(us.size());
+      for (size_t i = 0; i < us.size(); ++i) {
+        const UpdUnit& u = us[i];
+        int64_t k = 0;
+        if (u.nseg == 1) k = u.klen >= 0 ? u.klen : S.bcols[u.src_bcol0].width;
+        else for (int sg = 0; sg < u.nseg; ++sg) k += S.bcols[u.src_bcol0 + sg].width;
+        work[i] = k;
+      }
+      auto by_work = [&](const UpdTile& a, const UpdTile& b) { return work[a.unit - ubase] > work[b.unit - ubase]; };
+      std::stable_sort(t128.begin(), t128.end(), by_work);
+      std::stable_sort(t64.begin(), t64.end(), by_work);
+      std::stable_sort(t32.begin(), t32.end(), by_work);
     }
     double ntot = (double)t128.size() * 16 + (double)t64.size() * 4 + (double)t32.size();
     std::vector<UpdTile>* lists[3] = {&t128, &t64, &t32};
@@ -184,6 +210,7 @@ struct Builder {
       // 2*np-1 per block column) but runs one workgroup per CU; it pays where
       // the level is latency-bound (few, large nodes), not where thousands of
       // strips would queue.  Use it when all strips of a step fit in ~2 rounds.
+      std::vector<int> evB_hist;    // bulk event of every step of this level
       bool fs = la && opt.fused_strip;
       if (fs) {
         int64_t worst = 0;
@@ -199,6 +226,7 @@ struct Builder {
         }
         fs = worst <= opt.strip_limit;
       }
+      const bool lazy = la && !fs && opt.lazy_next;
       for (int c = 0; c < maxnc; ++c) {
         int maxp = 0;
         for (int s : nodes) {
@@ -253,9 +281,10 @@ struct Builder {
           }
         }
         for (int p = 0; p < maxp && !chained; ++p) {
-          // (1) left-looking update of panel p by the previous panels of the block column
+          // (1) left-looking update of panel p by the previous panels of the block
+          // column and (lazy_next) by the previous block column of the node
           double fl = 0;
-          if (p > 0) {
+          if (p > 0 || (lazy && c > 0)) {
             for (int s : nodes) {
               int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
               if (c >= nc) continue;
@@ -264,6 +293,30 @@ struct Builder {
               int c0 = p * pw;
               if (c0 >= B.width) continue;
               int pn = std::min(pw, B.width - c0);
+              if (lazy && c > 0) {
+                const BlockCol& Q = S.bcols[b - 1];
+                UpdUnit v{};
+                v.b_bcol0 = -1;
+                v.lower = 1;
+                v.mode = MODE_DIRECT;
+                v.d_off = B.off;
+                v.d_ld = B.width;
+                v.d_row0 = c0;
+                v.d_col0 = c0;
+                v.src_bcol0 = b - 1;
+                v.nseg = 1;
+                v.seg_r0 = Q.r0;
+                v.seg_stride = nb;
+                v.src_r0 = B.r0 + c0;
+                v.src_c0 = B.r0 + c0;
+                v.M = B.nrow - c0;
+                v.N = pn;
+                v.k0 = 0;
+                v.klen = Q.width;
+                us.push_back(v);
+                fl += 2.0 * Q.width * ((double)v.M * pn - 0.5 * pn * (pn - 1));
+              }
+              if (p == 0) continue;
               UpdUnit u{};
               u.b_bcol0 = -1;
               u.lower = 1;
@@ -286,7 +339,10 @@ struct Builder {
               fl += 2.0 * c0 * ((double)u.M * pn - 0.5 * pn * (pn - 1));
             }
             P.flops_update += fl;
-            emit_gemm(lev, us, fl);
+            Edge e1;
+            // the first launch of step c follows the bulk update (c-2 -> c..)
+            if (lazy && p == 0 && c >= 2) e1.wait0 = evB_hist[c - 2];
+            emit_gemm(lev, us, fl, true, e1);
           }
           // (2) POTRF of the diagonal panel blocks
           {
@@ -445,7 +501,9 @@ struct Builder {
             u.k0 = 0;
             u.klen = B.width;
             const double f1 = 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
-            if (la && jj > c + 1) {
+            if (lazy && jj == c + 1) {
+              continue;  // applied panel by panel in step c+1
+            } else if (la && jj > c + 1) {
               us_bulk.push_back(u);
               fl_bulk += f1;
             } else if (fs && jj == c + 1 && D.width <= 896 && D.nrow > D.width) {
@@ -496,6 +554,7 @@ struct Builder {
           }
           evB_prev = evB;
           evB1_prev = evB1;
+          evB_hist.push_back(evB);
         }
       }
 

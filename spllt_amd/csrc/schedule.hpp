@@ -120,6 +120,8 @@ struct ScheduleOptions {
   const int* node_owner = nullptr;
   bool lookahead = true;  // two-stream schedule: panel chain of block column c+1
                           // overlaps the trailing update by block column c
+  bool lazy_next = false;  // (lookahead, unfused) the update c -> c+1 is merged, panel by panel,
+                          // into the left-looking update launches of block column c+1
   bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
   int strip_limit = 512;    // ... on levels whose steps have at most this many strips
   bool tile_chain = true;   // with fused_strip: the panel chain of a diagonal tile (w <= 256)
