@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"])
     ap.add_argument("--nb", type=int, default=None)
     ap.add_argument("--panel", type=int, default=None)
+    ap.add_argument("--nemin", type=int, default=32, help="supernode amalgamation threshold (reference default 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-check", action="store_true")
@@ -134,7 +135,7 @@ def main():
         return
 
     t0 = time.time()
-    f = api.Factorization(n, ptr, row, nb=nb, nemin=32, prune_tree=False, order=order,
+    f = api.Factorization(n, ptr, row, nb=nb, nemin=args.nemin, prune_tree=False, order=order,
                           panel_width=args.panel,
                           engine_flags=int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")))
     t_analyse = time.time() - t0
@@ -192,10 +193,24 @@ def main():
         pass
     if args.profile_out:
         Lh = f.program("launches")
+        units, tiles = f.program("units"), f.program("tiles")
+        bc_off = f.sym("bcol_off")
+
+        def category(l):
+            if l[0] != 1:
+                return {0: "potrf", 3: "strip", 4: "chain", 5: "panelstep"}.get(int(l[0]), "other")
+            u = units[int(tiles[int(l[2])]["unit"])]
+            if u["mode"] == 2:
+                return "trsm"
+            if u["mode"] == 1:
+                return "between"
+            if bc_off[int(u["src_bcol0"])] == u["d_off"]:
+                return "inpanel"
+            return "next" if l[6] == 0 else "trailing"
         with open(args.profile_out, "w") as fh:
-            fh.write("idx kind level count tile gflop ms\n")
+            fh.write("idx kind level count tile gflop ms category\n")
             for i, (l, m) in enumerate(zip(Lh, ms)):
-                fh.write(f"{i} {l[0]} {l[1]} {l[3]} {l[4]} {l[5] / 1e9:.4f} {m:.4f}\n")
+                fh.write(f"{i} {l[0]} {l[1]} {l[3]} {l[4]} {l[5] / 1e9:.4f} {m:.4f} {category(l)}\n")
 
     cpu = None
     if not args.no_cpu_baseline:

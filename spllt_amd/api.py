@@ -29,6 +29,10 @@ UPD_UNIT_DTYPE = np.dtype([
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
 STRIP_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("row0", "<i4"),
                              ("nrows", "<i4"), ("pw", "<i4")])
+PANEL_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("d_off", "<i8"), ("s_off", "<i8"),
+                             ("ld", "<i4"), ("c0", "<i4"), ("pn", "<i4"), ("nrows", "<i4"),
+                             ("d_ld", "<i4"), ("d_c0", "<i4"), ("d_pn", "<i4"), ("d_rshift", "<i4"),
+                             ("s_ld", "<i4"), ("s_k", "<i4"), ("s_rshift", "<i4"), ("pad_", "<i4")])
 POTRF_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("n", "<i4"),
                              ("gcol", "<i4"), ("flags", "<i4")])
 
@@ -132,6 +136,8 @@ class Factorization:
             return raw.view(np.int32)
         if name == "strips":
             return raw.view(STRIP_UNIT_DTYPE)
+        if name == "panels":
+            return raw.view(PANEL_UNIT_DTYPE)
         if name == "dinv_size":
             return int(raw.view(np.int64)[0])
         return raw

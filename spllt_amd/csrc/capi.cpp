@@ -464,6 +464,7 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) 
   if (tile > 0) f->eo.tile = tile;
   f->eo.use_graph = (use_graph & 1) != 0;
   f->eo.lookahead = (use_graph & 2) == 0;  // bit 1 set: single-stream program
+  f->eo.panel_step = (use_graph & 32) != 0;  // bit 5 set: fused TRSM + next-panel update launches (k_panel_step)
   f->eo.lazy_next = (use_graph & 16) != 0;  // bit 4 set: c -> c+1 update merged into the panel updates of c+1
   f->eo.fused_strip = (use_graph & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
   f->eo.tile_chain = (use_graph & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
@@ -583,6 +584,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.tile = f->eo.tile;
     so.lookahead = f->eo.lookahead;
     so.lazy_next = f->eo.lazy_next;
+    so.panel_step = f->eo.panel_step;
     so.fused_strip = f->eo.fused_strip;
     so.tile_chain = f->eo.tile_chain;
     std::vector<int> owner;
@@ -614,6 +616,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
   if (k == "strips") return raw(P->strip_units.data(), P->strip_units.size() * sizeof(StripUnit));
+  if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelStepUnit));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(PotrfUnit));
   if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
   return -1;

@@ -58,6 +58,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
   so.lazy_next = opt_.lazy_next;
+  so.panel_step = opt_.panel_step;
   so.fused_strip = opt_.fused_strip;
   so.tile_chain = opt_.tile_chain;
   if (opt_.nranks > 1) {
@@ -144,6 +145,7 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_potrf_, prog_.potrf_units), "upload potrf units");
   HIPCHK(dev_upload(&d_strips_, prog_.strip_units), "upload strip units");
   HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
+  HIPCHK(dev_upload(&d_panels_, prog_.panel_units), "upload panel-step units");
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
@@ -159,7 +161,7 @@ Engine::~Engine() {
   if (graph_exec_) hipGraphExecDestroy(graph_exec_);
   if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_); hipFree(d_chain_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_); hipFree(d_chain_); hipFree(d_panels_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
@@ -180,6 +182,8 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     else if (l.kind == L_STRIP)
       launch_strip(st, l.tile, d_tiles_ + l.first, l.count, d_strips_, d_L_, d_dinv_);
+    else if (l.kind == L_PANEL)
+      launch_panel_step(st, d_tiles_ + l.first, l.count, d_panels_, d_L_, d_dinv_);
     else if (l.kind == L_CHAIN)
       launch_tile_chain(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     else {
@@ -188,7 +192,7 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       const bool two = !serial && opt_.lookahead;
       const int prio = (two && l.stream == 0) ? chain_prio_ : 0;
       int pad = 0;
-      if (two && l.stream == 1) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
+      if (two && l.stream == 1 && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
                     d_relpos_, d_rlist_, d_dinv_, prio, pad);
     }

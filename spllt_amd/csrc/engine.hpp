@@ -20,6 +20,7 @@ struct EngineOptions {
   int tile = 128;
   bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
+  bool panel_step = false; // fused TRSM + next-panel update launches on latency-bound levels
   bool lazy_next = false;  // merge the c -> c+1 update into the panel updates of c+1
   bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
   bool tile_chain = true;   // (with fused_strip) single-workgroup panel chain per diagonal tile
@@ -122,6 +123,7 @@ class Engine {
   PotrfUnit* d_potrf_ = nullptr;
   StripUnit* d_strips_ = nullptr;
   PotrfUnit* d_chain_ = nullptr;
+  PanelStepUnit* d_panels_ = nullptr;
   // device solve (built on first use)
   SolveProgram sprog_;
   bool solve_ready_ = false;

@@ -167,8 +167,15 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
     // row i; the four 16-lane groups hold identical copies, group 0 writes)
     if (w == 0) {
       double row[16];
+      // inv(D_J) rides along: lane c owns COLUMN c of W = inv(D_J); its forward
+      // substitution consumes the very scalars the factorization broadcasts
+      // (column j of D_J and 1/L_jj), so it only adds 16-j FMAs per step
+      double wacc[16], wx[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = T[(J * 16 + lr) * TLD + J * 16 + c];
+      for (int c = 0; c < 16; ++c) {
+        row[c] = T[(J * 16 + lr) * TLD + J * 16 + c];
+        wacc[c] = 0.0;
+      }
       int failcol = 1 << 30;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -187,47 +194,54 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
         const double sc = row[j] * (y * y);   // L_ij * y  (= row[j] * y^2)
         // unconditional: entries above the diagonal (lr < k) become garbage
         // that nothing reads (the write-back masks them)
+        // W[j][c] = (delta_jc - sum_{k<j} L_jk W[k][c]) / L_jj ;  L_kj = tk[k] * y
+        wx[j] = (((lr == j) ? 1.0 : 0.0) - wacc[j]) * y;
+        const double z = wx[j] * y;
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) row[k] -= sc * tk[k];
+        for (int k = j + 1; k < 16; ++k) {
+          row[k] -= sc * tk[k];
+          wacc[k] = __builtin_fma(tk[k], z, wacc[k]);   // same broadcast scalar, used twice
+        }
         row[j] = (lr == j) ? d : row[j] * y;
         RI[J * 16 + j] = y;  // wave-uniform value, every lane stores the same word
+        // pin W[j][.] here: it is only stored by lanes < 16 below, and without the
+        // pin the whole inverse recurrence is sunk into that branch, which keeps
+        // every broadcast scalar of every step alive (SGPR spills)
+        asm volatile("" : "+v"(wx[j]));
       }
       if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) T[(J * 16 + lr) * TLD + J * 16 + c] = (c <= lr) ? row[c] : 0.0;
+        for (int c = 0; c < 16; ++c) {
+          T[(J * 16 + lr) * TLD + J * 16 + c] = (c <= lr) ? row[c] : 0.0;
+          DI[J][c * DLD + lr] = wx[c];
+          X[(J * 16 + c) * TLD + J * 16 + lr] = wx[c];
+        }
         if (failcol != (1 << 30) && lane == 0) atomicMin(flag, u.gcol + J * 16 + failcol + 1);
       }
     }
     __syncthreads();
     STAMP(3 + 3 * J);
-    // A3: rows of the sub-blocks below: x = a * D_J^-T by forward substitution
-    // (lane i owns row i of sub-block I; D_J and its reciprocals come from LDS)
+    // A3: sub-blocks below: X_IJ = A_IJ * inv(D_J)^T on the matrix core
     {
       const int I = J + 1 + w;
       if (I < nblk) {
-        double x[16];
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = T[(I * 16 + lr) * TLD + J * 16 + c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double sacc = x[c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) sacc -= x[k] * T[(J * 16 + c) * TLD + J * 16 + k];
-          x[c] = sacc * RI[J * 16 + c];
+        for (int t = 0; t < 4; ++t) {
+          const double a = T[(I * 16 + lr) * TLD + J * 16 + 4 * t + lq];
+          const double b = DI[J][lr * DLD + 4 * t + lq];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) T[(I * 16 + lr) * TLD + J * 16 + c] = x[c];
-        }
+        st_c(T, I * 16, J * 16, lane, acc);
       }
     }
     __syncthreads();
     STAMP(4 + 3 * J);
   }
-  // B0: invert the diagonal 16x16 blocks, one per wave: lane c owns COLUMN c of
-  // inv(D_w) and solves D_w x = e_c by forward substitution; the entries of D_w
-  // are wave-uniform LDS reads, so no cross-lane traffic is needed
-  if (w < nblk) {
+  // B0 (invert-only blocks): invert the diagonal 16x16 blocks, one per wave: lane c
+  // owns COLUMN c of inv(D_w) and solves D_w x = e_c by forward substitution; the
+  // entries of D_w are wave-uniform LDS reads, so no cross-lane traffic is needed
+  if (!do_chol && w < nblk) {
     double x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -400,6 +414,148 @@ __global__ __launch_bounds__(256) void k_tile_chain(const PotrfUnit* __restrict_
     __syncthreads();
     slot += (int64_t)pn * pn;
   }
+}
+
+// ---------------------------------------------------------------------------
+// One panel step below its POTRF (PanelStepUnit).  Workgroup = 32 rows:
+//   Xi = A_i * inv(L_pp)^T                     (the TRSM of its rows, stored)
+//   Xd = A_d * inv(L_pp)^T                     (rows of the next panel's diagonal
+//                                               block, recomputed by every workgroup)
+//   D[i, next panel] -= [S_i | O_i | Xi] * [S_d | O_d | Xd]^T
+// with S = previous block column, O = source block column's panels before p
+// (MFMA operands straight from global/L2) and the panel itself from LDS.  It
+// replaces the TRSM launch, the left-looking update launch of the next panel
+// and the separate block-column c -> c+1 update on the critical path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_panel_step(const UpdTile* __restrict__ tiles,
+                                                    const PanelStepUnit* __restrict__ units,
+                                                    double* __restrict__ L,
+                                                    const double* __restrict__ dinv) {
+  __shared__ double Ai[32 * TLD];
+  __shared__ double Ad[64 * TLD];
+  __builtin_amdgcn_s_setprio(2);
+  const UpdTile tl = tiles[blockIdx.x];
+  const PanelStepUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int pn = u.pn, ld = u.ld;
+  const int rb = u.c0 + pn;          // first stored row below the diagonal block
+  const int i0 = tl.ti * 32;         // first row of this tile inside the region
+  const bool has_dest = u.d_off >= 0;
+  const double* A = L + u.off;
+  // ---- stage A_i (32 x pn) and A_d (d_pn x pn), zero padded ----------------
+  {
+    const int r = tid >> 3, k0 = (tid & 7) * 8;
+    const bool ok = i0 + r < u.nrows;
+    const double* src = A + (int64_t)(rb + (ok ? i0 + r : 0)) * ld + u.c0;
+    double v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[min(k0 + e, pn - 1)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Ai[r * TLD + k0 + e] = (ok && k0 + e < pn) ? v[e] : 0.0;
+  }
+  if (has_dest) {
+    const int r = tid >> 2, k0 = (tid & 3) * 16;
+    const bool ok = r < u.d_pn;
+    const double* src = A + (int64_t)(rb + (ok ? r : 0)) * ld + u.c0;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = src[min(k0 + e, pn - 1)];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ad[r * TLD + k0 + e] = (ok && k0 + e < pn) ? v[e] : 0.0;
+  }
+  __syncthreads();
+  // ---- Xi, Xd = A * Dinv^T ---------------------------------------------------
+  const double* D = dinv + u.dinv_off;
+  const int rf = w & 1, cfb = (w >> 1) * 2;   // Xi / update fragments of this wave: (rf, cfb), (rf, cfb+1)
+  d4 xd[4], xi[2];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf) {
+    double bv[16];
+    const int jrow = min(cf * 16 + lr, pn - 1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) bv[t] = D[jrow * pn + min(4 * t + lq, pn - 1)];
+    const bool jok = cf * 16 + lr < pn;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    d4 acci = {0.0, 0.0, 0.0, 0.0};
+    const bool mine = (cf >> 1) == (w >> 1);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const double b = (jok && 4 * t + lq < pn) ? bv[t] : 0.0;
+      if (has_dest) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[(w * 16 + lr) * TLD + 4 * t + lq], b, acc, 0, 0, 0);
+      if (mine) acci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(rf * 16 + lr) * TLD + 4 * t + lq], b, acci, 0, 0, 0);
+    }
+    xd[cf] = acc;
+    if (mine) xi[cf & 1] = acci;
+  }
+  __syncthreads();
+  // ---- write back: Xd -> Ad, Xi -> Ai and L (final values of the panel rows) --
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ad[(w * 16 + lq + 4 * r) * TLD + cf * 16 + lr] = xd[cf][r];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rf * 16 + lq + 4 * r, col = (cfb + c) * 16 + lr;
+      Ai[row * TLD + col] = xi[c][r];
+      if (i0 + row < u.nrows && col < pn)
+        L[u.off + (int64_t)(rb + i0 + row) * ld + u.c0 + col] = xi[c][r];
+    }
+  if (!has_dest) return;
+  __syncthreads();
+  // ---- update of the next panel ------------------------------------------------
+  d4 acc[2];
+  acc[0] = (d4){0.0, 0.0, 0.0, 0.0};
+  acc[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const double a = Ai[(rf * 16 + lr) * TLD + 4 * t + lq];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ad[((cfb + 0) * 16 + lr) * TLD + 4 * t + lq], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ad[((cfb + 1) * 16 + lr) * TLD + 4 * t + lq], acc[1], 0, 0, 0);
+  }
+  const bool aok = i0 + rf * 16 + lr < u.nrows;
+  const int arow = rb + (aok ? i0 + rf * 16 + lr : 0);
+  const bool b0ok = (cfb + 0) * 16 + lr < u.d_pn, b1ok = (cfb + 1) * 16 + lr < u.d_pn;
+  const int b0row = rb + (b0ok ? (cfb + 0) * 16 + lr : 0);
+  const int b1row = rb + (b1ok ? (cfb + 1) * 16 + lr : 0);
+  for (int sg = 0; sg < 2; ++sg) {
+    // sg 0: the source block column's panels before p;  sg 1: the previous block column
+    const int K = sg == 0 ? u.c0 : (u.s_off >= 0 ? u.s_k : 0);
+    if (K <= 0) continue;
+    const int sld = sg == 0 ? ld : u.s_ld;
+    const int rsh = sg == 0 ? 0 : u.s_rshift;
+    const double* base = L + (sg == 0 ? u.off : u.s_off);
+    const double* pa = base + (int64_t)(arow + rsh) * sld + lq;
+    const double* p0 = base + (int64_t)(b0row + rsh) * sld + lq;
+    const double* p1 = base + (int64_t)(b1row + rsh) * sld + lq;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      double av[16], v0[16], v1[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int k = min(k0 + 4 * t, K - 4 + 3 - lq);   // stays inside the row: k + lq <= K - 1
+        av[t] = pa[k];
+        v0[t] = p0[k];
+        v1[t] = p1[k];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bool kok = k0 + 4 * t + lq < K;
+        const double a = (aok && kok) ? av[t] : 0.0;
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (b0ok && kok) ? v0[t] : 0.0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (b1ok && kok) ? v1[t] : 0.0, acc[1], 0, 0, 0);
+      }
+    }
+  }
+  double* Dst = L + u.d_off;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + rf * 16 + lq + 4 * r, j = (cfb + c) * 16 + lr;
+      if (i < u.nrows && j < u.d_pn && i >= j)
+        unsafeAtomicAdd(Dst + (int64_t)(rb + i - u.d_rshift) * u.d_ld + u.d_c0 + j, -acc[c][r]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -975,6 +1131,12 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
   else
     hipLaunchKernelGGL((k_update<32, 32, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
                        units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+}
+
+void launch_panel_step(hipStream_t st, const UpdTile* tiles, int64_t count,
+                       const PanelStepUnit* units, double* L, const double* dinv) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_panel_step, dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
 }
 
 void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,

@@ -26,6 +26,10 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,
                           double* dest, int ldd);
 
+// fused TRSM + next-panel update (tiles: unit, ti = 32-row tile of the rows below the panel)
+void launch_panel_step(hipStream_t st, const UpdTile* tiles, int64_t count,
+                       const PanelStepUnit* units, double* L, const double* dinv);
+
 // rs = rows per strip: 32 (block column width <= 320) or 16 (<= 896)
 void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
                   const StripUnit* units, double* L, const double* dinv);

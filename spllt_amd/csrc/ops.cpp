@@ -137,6 +137,7 @@ int spllt_factor_diag_block_hip(void* stream, int m, int n, double* bc, int* dev
   OpsBatch B;
   ScheduleOptions so;
   so.lookahead = false;  // one stream, program order
+  so.panel_step = false; // the operator twins run the unfused POTRF / TRSM / UPDATE launches
   build_program(S, so, B.P);
   B.bc_off = {S.bcols[0].off};
   B.bc_w = {n};

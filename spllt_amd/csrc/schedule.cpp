@@ -9,7 +9,7 @@ namespace spx {
 namespace {
 
 struct Edge {
-  int stream = 0, wait0 = -1, wait1 = -1, record = -1;
+  int stream = 0, wait0 = -1, wait1 = -1, record = -1, overlap = 0;
 };
 
 static int64_t env_int(const char* name, int64_t dflt) {
@@ -140,6 +140,7 @@ struct Builder {
       L.wait0 = pass == first_nonempty ? e.wait0 : -1;
       L.wait1 = pass == first_nonempty ? e.wait1 : -1;
       L.record = pass == last_nonempty ? e.record : -1;
+      L.overlap = e.overlap;
       P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
       P.launches.push_back(L);
     }
@@ -226,7 +227,24 @@ struct Builder {
         }
         fs = worst <= opt.strip_limit;
       }
-      const bool lazy = la && !fs && opt.lazy_next;
+      // fused panel steps (k_panel_step): TRSM + every missing update of the next
+      // 64-wide panel in one launch, on levels whose steps are latency-bound
+      bool ps = !fs && opt.panel_step;
+      if (ps) {
+        int64_t worst = 0;
+        for (int c = 0; c < maxnc; ++c) {
+          int64_t t = 0;
+          for (int s : nodes) {
+            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c >= nc) continue;
+            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
+            t += cdiv(std::max(0, B.nrow - std::min(pw, B.width)), 32);
+          }
+          worst = std::max(worst, t);
+        }
+        ps = worst <= opt.panel_step_limit;
+      }
+      const bool lazy = la && !fs && !ps && opt.lazy_next;
       for (int c = 0; c < maxnc; ++c) {
         int maxp = 0;
         for (int s : nodes) {
@@ -284,7 +302,7 @@ struct Builder {
           // (1) left-looking update of panel p by the previous panels of the block
           // column and (lazy_next) by the previous block column of the node
           double fl = 0;
-          if (p > 0 || (lazy && c > 0)) {
+          if (!ps && (p > 0 || (lazy && c > 0))) {
             for (int s : nodes) {
               int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
               if (c >= nc) continue;
@@ -377,8 +395,87 @@ struct Builder {
             if (la && first_of_level) {
               L.wait0 = ev_level;  // everything of the previous level (incl. its bulk stream)
               first_of_level = false;
+            } else if (la && ps && p == 0 && c >= 2) {
+              L.wait0 = evB_hist[c - 2];  // bulk update (c-2 -> c..) precedes the first panel of c
             }
             if (L.count > 0) P.launches.push_back(L);
+          }
+          // (3p) fused panel step: TRSM of the rows below + update of the next panel
+          if (ps) {
+            Launch L;
+            L.kind = L_PANEL;
+            L.level = lev;
+            L.first = (int64_t)P.tiles.size();
+            L.tile = 32;
+            fl = 0;
+            for (int s : nodes) {
+              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              int c0 = p * pw;
+              if (c0 >= B.width) continue;
+              int pn = std::min(pw, B.width - c0);
+              int rows = B.nrow - (c0 + pn);
+              if (rows <= 0) continue;
+              PanelStepUnit q{};
+              q.off = B.off;
+              q.ld = B.width;
+              q.c0 = c0;
+              q.pn = pn;
+              q.nrows = rows;
+              int64_t slot = dinv_slot[b];
+              for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
+              q.dinv_off = slot;
+              q.d_off = -1;
+              q.s_off = -1;
+              double kk = 0;  // K extent of the update (global segments + the panel)
+              if (c0 + pn < B.width) {
+                // next panel in the same block column: previous block column + own panels
+                q.d_off = B.off;
+                q.d_ld = B.width;
+                q.d_c0 = c0 + pn;
+                q.d_pn = std::min(pw, B.width - (c0 + pn));
+                q.d_rshift = 0;
+                kk = c0 + pn;
+                if (c > 0) {
+                  const BlockCol& Q = S.bcols[b - 1];
+                  q.s_off = Q.off;
+                  q.s_ld = Q.width;
+                  q.s_k = Q.width;
+                  q.s_rshift = Q.width;
+                  kk += Q.width;
+                }
+              } else if (c + 1 < nc) {
+                // panel 0 of the next block column: this block column's panels
+                const BlockCol& Dn = S.bcols[b + 1];
+                q.d_off = Dn.off;
+                q.d_ld = Dn.width;
+                q.d_c0 = 0;
+                q.d_pn = std::min(pw, Dn.width);
+                q.d_rshift = B.width;
+                kk = c0 + pn;
+              }
+              int uid = (int)P.panel_units.size();
+              P.panel_units.push_back(q);
+              for (int t = 0; t < cdiv(rows, 32); ++t) {
+                UpdTile tt;
+                tt.unit = uid;
+                tt.ti = (short)t;
+                tt.tj = 0;
+                P.tiles.push_back(tt);
+              }
+              const double ft = (double)rows * pn * pn;
+              double fu = 0;
+              if (q.d_off >= 0) fu = 2.0 * kk * ((double)rows * q.d_pn - 0.5 * q.d_pn * (q.d_pn - 1));
+              P.flops_trsm += ft;
+              P.flops_update += fu;
+              fl += ft + fu;
+            }
+            L.count = (int64_t)P.tiles.size() - L.first;
+            L.flops = fl;
+            if (L.count > 0) P.launches.push_back(L);
+            continue;
           }
           // (3) TRSM of the rows below the panel: X = A * inv(Lpp)^T (in place)
           fl = 0;
@@ -501,7 +598,7 @@ struct Builder {
             u.k0 = 0;
             u.klen = B.width;
             const double f1 = 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
-            if (lazy && jj == c + 1) {
+            if ((lazy || ps) && jj == c + 1) {
               continue;  // applied panel by panel in step c+1
             } else if (la && jj > c + 1) {
               us_bulk.push_back(u);
@@ -537,6 +634,7 @@ struct Builder {
           if (!us_rest.empty()) {
             Edge e1;
             e1.stream = 1;
+            e1.overlap = 1;
             e1.wait0 = evP;
             waited = true;
             evB1 = P.nevents++;
@@ -547,6 +645,7 @@ struct Builder {
           if (!us_bulk.empty()) {
             Edge e1;
             e1.stream = 1;
+            e1.overlap = 1;
             e1.wait0 = waited ? -1 : evP;
             evB = P.nevents++;
             e1.record = evB;

@@ -78,7 +78,29 @@ struct StripUnit {
   int pw;            // panel width
 };
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3, L_CHAIN = 4 };
+// One panel step of the chain below its POTRF, fused (k_panel_step): the rows
+// below panel p of a block column are solved against inv(L_pp) and the NEXT
+// 64-wide panel of the node (same block column, or panel 0 of the next block
+// column) receives every update that is still missing: the previous block
+// column (s_*), the source block column's panels before p (global) and panel p
+// itself (straight from LDS).  Row coordinates are stored rows of the source
+// block column.
+struct PanelStepUnit {
+  int64_t off;       // arena offset of the source block column
+  int64_t dinv_off;  // inv(L_pp) in the dinv scratch (row-major, ld = pn)
+  int64_t d_off;     // arena offset of the destination block column (-1: no next panel)
+  int64_t s_off;     // arena offset of the previous block column (-1: none)
+  int ld;            // source block column width
+  int c0, pn;        // panel p: first column, width
+  int nrows;         // rows below the panel's diagonal block
+  int d_ld, d_c0, d_pn;  // destination row width, first column, panel width
+  int d_rshift;      // destination stored row = source stored row - d_rshift
+  int s_ld, s_k;     // previous block column: row width, K extent
+  int s_rshift;      // previous block column stored row = source stored row + s_rshift
+  int pad_;
+};
+
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3, L_CHAIN = 4, L_PANEL = 5 };
 
 struct Launch {
   int kind;
@@ -92,11 +114,13 @@ struct Launch {
   int stream = 0;
   int wait0 = -1, wait1 = -1;
   int record = -1;
+  int overlap = 0;  // 1: bulk launch that runs beside a panel chain (engine may cap its CU share)
 };
 
 struct Program {
   int pw = 64;  // inner panel width
   std::vector<PotrfUnit> potrf_units;
+  std::vector<PanelStepUnit> panel_units;  // L_PANEL (tiles: unit, ti = 32-row tile)
   std::vector<PotrfUnit> chain_units;  // L_CHAIN: off = block column, n = tile order, flags = panel width
   std::vector<UpdUnit> units;
   std::vector<UpdTile> tiles;
@@ -122,6 +146,8 @@ struct ScheduleOptions {
                           // overlaps the trailing update by block column c
   bool lazy_next = false;  // (lookahead, unfused) the update c -> c+1 is merged, panel by panel,
                           // into the left-looking update launches of block column c+1
+  bool panel_step = false;  // fused TRSM + next-panel update launches (k_panel_step) on levels
+  int panel_step_limit = 768;  // ... whose steps have at most this many 32-row tiles
   bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
   int strip_limit = 512;    // ... on levels whose steps have at most this many strips
   bool tile_chain = true;   // with fused_strip: the panel chain of a diagonal tile (w <= 256)

@@ -87,6 +87,44 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 arena[off + r0 * w: off + (r0 + nr) * w] = sl.solve_triangular(
                     Lt, rows.T, lower=True).T.ravel()
             continue
+        if kind == 5:  # fused panel step: TRSM of the rows below + update of the next panel
+            panels = f.program("panels")
+            tl = tiles[first:first + count]
+            for t in tl:  # pass 1: X = A * inv(L_pp)^T
+                q = panels[int(t["unit"])]
+                ld, off, c0, pn = int(q["ld"]), int(q["off"]), int(q["c0"]), int(q["pn"])
+                D = dinv[int(q["dinv_off"]):int(q["dinv_off"]) + pn * pn].reshape(pn, pn)
+                r0 = c0 + pn + int(t["ti"]) * 32
+                nr = min(32, c0 + pn + int(q["nrows"]) - r0)
+                assert nr > 0
+                idx = off + (r0 + np.arange(nr))[:, None] * ld + c0 + np.arange(pn)[None, :]
+                arena[idx] = arena[idx] @ D.T
+            for t in tl:  # pass 2: next panel -= [S | O | X]_i [S | O | X]_d^T
+                q = panels[int(t["unit"])]
+                if q["d_off"] < 0:
+                    continue
+                ld, off, c0, pn = int(q["ld"]), int(q["off"]), int(q["c0"]), int(q["pn"])
+                rb, dpn = c0 + pn, int(q["d_pn"])
+                i0 = int(t["ti"]) * 32
+                nr = min(32, int(q["nrows"]) - i0)
+
+                def rows_of(r_first, cnt):
+                    parts = []
+                    if q["s_off"] >= 0:
+                        sld, sk, rsh = int(q["s_ld"]), int(q["s_k"]), int(q["s_rshift"])
+                        ii = int(q["s_off"]) + (r_first + rsh + np.arange(cnt))[:, None] * sld + np.arange(sk)[None, :]
+                        parts.append(arena[ii])
+                    ii = off + (r_first + np.arange(cnt))[:, None] * ld + np.arange(c0 + pn)[None, :]
+                    parts.append(arena[ii])
+                    return np.hstack(parts)
+                P = rows_of(rb + i0, nr) @ rows_of(rb, dpn).T
+                ii = np.arange(nr)[:, None] + i0
+                jj = np.arange(dpn)[None, :]
+                keep = ii >= jj
+                idx = (int(q["d_off"]) + (rb + ii - int(q["d_rshift"])) * int(q["d_ld"]) +
+                       int(q["d_c0"]) + jj)
+                arena[idx[keep]] -= P[keep]
+            continue
         if kind == 0:
             for q in potrf[first:first + count]:
                 n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])

@@ -40,6 +40,8 @@ CASES = [
     ("p3d20-nb384", lambda: matgen.poisson3d(20), 384, 32, None),    # config 3 tile size
     ("fe27-nb512", lambda: matgen.fe27((9, 8, 8), 3), 512, 32, None),   # config 4 tile size / pattern
     ("fe27-nb768", lambda: matgen.fe27((10, 9, 9), 3), 768, 32, None),  # config 5 tile size / pattern
+    ("box11-nb100-pw48", lambda: matgen.nd_like((11, 10, 10), 3), 100, 16, 48),  # ragged panels
+    ("p3d15-nb192-pw64", lambda: matgen.poisson3d(15), 192, 24, 64),
 ]
 
 
@@ -338,12 +340,15 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("flags", [2, 4, 12])
+@pytest.mark.parametrize("flags", [2, 4, 12, 16, 32, 34])
 def test_engine_variants_match_oracle(flags):
     """single-stream program (2), fused strip-TRSM + tile lookahead with the
-    single-workgroup tile chain (4) and with per-panel launches (12)."""
+    single-workgroup tile chain (4) and with per-panel launches (12), lazy
+    next-column update (16), separate TRSM / update launches instead of the
+    fused panel steps (32, 34)."""
     A = matgen.nd_like((12, 11, 10), 2)
     f, val = make_case(A, nb=64, nemin=16, panel_width=32, engine_flags=flags)
+    assert ((f.program("launches")[:, 0] == 5).any()) == (flags in (32, 34))
     got = f.factor(val).wait().get_factor()
     o, rc = oracle_factor(f, val)
     assert rc == 0

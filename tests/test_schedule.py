@@ -173,7 +173,22 @@ def _access_sets(f):
                 elif u["mode"] == 1:
                     At |= {2 * db, 2 * db + 1}
                 else:
-                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
+                    # DIRECT updates subtract with L2 atomics (k_update epilogue)
+                    At |= parts(db, int(u["d_row0"]), int(u["M"]))
+        elif kind == 5:
+            panels = f.program("panels")
+            for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
+                q = panels[uid]
+                b = int(np.searchsorted(off, q["off"], side="right") - 1)
+                rb, nr = int(q["c0"]) + int(q["pn"]), int(q["nrows"])
+                R |= parts(b, rb, nr) | {2 * b, 2 * nbc + b}
+                W |= parts(b, rb, nr)
+                if q["s_off"] >= 0:
+                    sb = int(np.searchsorted(off, q["s_off"], side="right") - 1)
+                    R |= parts(sb, rb + int(q["s_rshift"]), nr)
+                if q["d_off"] >= 0:
+                    db = int(np.searchsorted(off, q["d_off"], side="right") - 1)
+                    At |= parts(db, rb - int(q["d_rshift"]), nr)
         out.append((R, W, At))
     return launches, out
 
@@ -181,7 +196,7 @@ def _access_sets(f):
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
                                         (lambda: matgen.poisson3d(9), 24, 8)])
-@pytest.mark.parametrize("flags", [0, 4, 12])
+@pytest.mark.parametrize("flags", [0, 4, 12, 16, 32])
 def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     """Two-stream lookahead program: any two launches that touch the same block
     column (write/write, read/write, atomic/plain) must be ordered by stream
@@ -193,6 +208,7 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert ((launches[:, 0] == 3).any()) == (flags in (4, 12)), "fused strip launches only with flag 4"
     assert ((launches[:, 0] == 4).any()) == (flags == 4), "tile-chain launches with flag 4 (bit 3 disables)"
+    assert ((launches[:, 0] == 5).any()) == (flags == 32), "fused panel steps with bit 5 (not in strip mode)"
     rec_at = {}
     last_in_stream = {}
     before = [0] * n  # bitset of launches that happen-before launch i
@@ -231,7 +247,7 @@ def test_single_stream_program_has_no_events():
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
-@pytest.mark.parametrize("flags", [0, 4, 2, 6, 12])
+@pytest.mark.parametrize("flags", [0, 4, 2, 6, 12, 16, 32, 34])
 def test_program_variants_agree(flags):
     """fused strip / per-panel TRSM, two-stream / single-stream programs all
     reproduce the same factor (interpreted in numpy)."""
@@ -239,5 +255,7 @@ def test_program_variants_agree(flags):
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
     L = f.program("launches")
     assert ((L[:, 0] == 3).any()) == (flags in (4, 12))   # strip kernel needs the two-stream program
+    # fused panel steps with bit 5 unless the strip mode (bit 2, two-stream only) is active
+    assert ((L[:, 0] == 5).any()) == (bool(flags & 32) and not ((flags & 4) and not (flags & 2)))
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
