@@ -12,32 +12,36 @@ then factorized on every rank (v1: replicated; SURVEY 8(e) "top tree v1").
 
 torch is used only for device memory and torch.distributed (plumbing).
 """
+import os
 import time
 
 import numpy as np
 
 
-def reduce_exchange_buffer(xbuf):
-    """Sum the packed top-tree block columns over all ranks (in place).
+def reduce_exchange_buffer(xbuf, group=None):
+    """Sum the packed top-tree block columns over the ranks of `group` (in place).
     backend nccl == RCCL on ROCm; the same call runs on gloo for the CPU tests."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(xbuf, op=dist.ReduceOp.SUM)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(xbuf, op=dist.ReduceOp.SUM, group=group)
     return xbuf
 
 
 class DistributedFactorization:
-    """Factorization of one pattern on `world` GPUs (this process = `rank`)."""
+    """Factorization of one pattern on `world` GPUs (this process = `rank` of
+    the process group `group`).  world == 1 is the plain single-GPU engine."""
 
-    def __init__(self, n, ptr, row, nb, rank, world, order=None, nemin=32, panel_width=None):
+    def __init__(self, n, ptr, row, nb, rank, world, order=None, nemin=32, panel_width=None,
+                 group=None):
         import torch
         from . import api
-        self.rank, self.world = rank, world
-        self.f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=True, ncpu=world,
-                                   order=order, panel_width=panel_width)
-        self.xelems = self.f.set_partition(rank, world)
+        self.rank, self.world, self.group = rank, world, group
+        self.f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=world > 1,
+                                   ncpu=world, order=order, panel_width=panel_width)
+        self.xelems = self.f.set_partition(rank, world) if world > 1 else 0
         self.xbuf = torch.zeros(max(self.xelems, 1), dtype=torch.float64, device="cuda")
-        self.f.set_exchange_buffer(self.xbuf.data_ptr())
+        if world > 1:
+            self.f.set_exchange_buffer(self.xbuf.data_ptr())
         self.phase_ms = {}
 
     def factor(self, dval):
@@ -48,7 +52,7 @@ class DistributedFactorization:
         self.f.wait()                      # own subtrees done, top tree packed
         t1 = time.perf_counter()
         if self.world > 1:
-            reduce_exchange_buffer(self.xbuf)
+            reduce_exchange_buffer(self.xbuf, self.group)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             self.f.continue_after_exchange()
@@ -60,70 +64,82 @@ class DistributedFactorization:
                          "top": (t3 - t2) * 1e3}
         return self
 
+    def close(self):
+        self.f.close()
 
-def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
-    """bench.py body for N > 1 (strong scaling: one factorization, N GPUs)."""
+
+def _timed(df, dval, steps, active):
+    """max-over-ranks wall time of `steps` factorizations by the active ranks
+    (idle ranks only take part in the barriers)."""
     import torch
     import torch.distributed as dist
-    df = DistributedFactorization(n, ptr, row, nb, rank, world, order=order,
-                                  panel_width=args.panel)
-    si = df.f.sym_info()
-    flops = float(si["flops"])
-    dval = torch.tensor(val, device="cuda")
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        df.factor(dval)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        df.factor(dval)
+    if active:
+        for _ in range(steps):
+            df.factor(dval)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    t_total = float(dt.item())
-    # accuracy gate on rank 0: gather the subtree block columns, solve, residual
-    owner = df.f.partition("owner")
-    own_w = np.zeros(world)
-    w = df.f.sym("weight")
-    small = df.f.sym("small")
-    for s in range(len(owner)):
-        if small[s] == 1:
-            own_w[owner[s]] += w[s]
-    top_flops = flops - own_w.sum()
-    check = {}
+    return float(dt.item())
+
+
+def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
+    """bench.py body for N > 1 (strong scaling: one factorization, N GPUs).
+
+    The tree-level partition has one knob, its width w <= N (the
+    subtrees shard, the top tree does not): w ranks own subtrees and run the
+    exchange, the others idle.  A wider partition shortens the subtree phase
+    but grows the replicated top tree and the exchange, so the width is
+    measured, not assumed: every power of two w <= N (and N) is timed during
+    warm-up and the fastest one runs the timed steps."""
+    import torch
+    import torch.distributed as dist
+    widths = sorted({w for w in (1, 2, 4, 8, 16, world) if w <= world})
+    forced = int(os.environ.get("SPLLT_PARTITION_WIDTH", "0"))
+    if forced:
+        widths = [min(max(forced, 1), world)]
+    dval = torch.tensor(val, device="cuda")
+    trial = {}
+    best_w, best_t, best = None, None, None
+    for w in widths:
+        group = dist.new_group(ranks=list(range(w))) if 1 < w < world else None
+        active = rank < w
+        df = None
+        if active:
+            df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
+                                          panel_width=args.panel, group=group)
+        _timed(df, dval, 1, active)                      # first touch
+        t = _timed(df, dval, max(1, args.warmup), active) / max(1, args.warmup)
+        trial[w] = round(t * 1e3, 3)
+        if best_t is None or t < best_t:
+            if best is not None:
+                best.close()
+            best_w, best_t, best = w, t, df
+        elif df is not None:
+            df.close()
+    w = best_w
+    active = rank < w
+    df = best
+    t_total = _timed(df, dval, args.steps, active)
+    si_t = torch.zeros(4, dtype=torch.float64, device="cuda")
+    if rank == 0:
+        si = df.f.sym_info()
+        si_t = torch.tensor([si["flops"], si["nnz_l"], si["nnodes"], df.xelems], dtype=torch.float64,
+                            device="cuda")
+    flops = float(si_t[0].item()) if rank == 0 else 0.0
+    check, own_w, top_flops = {}, np.zeros(max(w, 1)), 0.0
+    if active and w > 1:
+        owner = df.f.partition("owner")
+        wgt, small = df.f.sym("weight"), df.f.sym("small")
+        for s in range(len(owner)):
+            if small[s] == 1:
+                own_w[owner[s]] += wgt[s]
+        top_flops = float(df.f.sym_info()["flops"]) - own_w.sum()
     if not args.no_check:
-      # step 1 (local, may fail on one rank only): fetch this rank's part of L;
-      # agree on success before entering the collective so that no rank hangs
-      L, ok = None, 1
-      try:
-        L = torch.tensor(df.f.get_factor(), dtype=torch.float64, device="cuda")
-      except Exception as e:
-        ok, check = 0, {"error": repr(e)[:200]}
-      okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
-      dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-      if int(okt.item()) == 1:
-       try:
-        # every rank holds its own subtrees + the whole top tree; non-owned
-        # subtree block columns are zero, so a sum assembles L on every rank
-        # once the (replicated) top tree is counted only from rank 0
-        bc_node = df.f.sym("bcol_node")
-        off, wdt, nrw = df.f.sym("bcol_off"), df.f.sym("bcol_width"), df.f.sym("bcol_nrow")
-        if rank != 0:
-            for b in np.where(owner[bc_node] < 0)[0]:
-                L[int(off[b]):int(off[b]) + int(nrw[b]) * int(wdt[b])] = 0
-        dist.all_reduce(L, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            Lh = L.cpu().numpy()
-            x = _host_solve(df.f, Lh, A @ np.ones(n))
-            b = A @ np.ones(n)
-            r = b - A @ x
-            check = {"resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
-                     "bwd_err": float(np.linalg.norm(r) /
-                                      (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
-       except Exception as e:  # the accuracy gate must never take the benchmark line down
-        check = {"error": repr(e)[:200]}
+        check = _accuracy_gate(df, A, n, rank, w, active)
     out = None
     if rank == 0:
         out = {
@@ -132,16 +148,59 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_total / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": name, "n": n, "nb": nb, "nnz_L": int(si["nnz_l"]),
-                       "flops_sym": flops, "nnodes": int(si["nnodes"]),
-                       "parallelism": f"subtree partition over {world} GPUs + RCCL all-reduce "
-                                      "extend-add, replicated top tree"},
+            "config": {"workload": name, "n": n, "nb": nb, "nnz_L": int(si_t[1].item()),
+                       "flops_sym": flops, "nnodes": int(si_t[2].item()),
+                       "parallelism": f"subtree partition of width {w} over {world} GPUs (width "
+                                      "measured during warm-up) + RCCL all-reduce extend-add, "
+                                      "replicated top tree"},
             "roofline": None, "cpu_baseline": None,
-            "detail": {"phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
+            "detail": {"partition_width": w, "width_trials_ms": trial,
+                       "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
                        "subtree_gflop_per_rank": (own_w / 1e9).round(1).tolist(),
                        "top_tree_gflop": round(top_flops / 1e9, 1), "check": check},
         }
     return out
+
+
+def _accuracy_gate(df, A, n, rank, w, active):
+    """Assemble L on rank 0 of the partition, solve, report the residuals.  Never
+    raises and never leaves a rank behind in a collective."""
+    import torch
+    import torch.distributed as dist
+    check = {}
+    L, ok = None, 1
+    if active:
+        try:
+            L = torch.tensor(df.f.get_factor(), dtype=torch.float64, device="cuda")
+        except Exception as e:
+            ok, check = 0, {"error": repr(e)[:200]}
+    okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if int(okt.item()) != 1 or not active:
+        return check
+    try:
+        if w > 1:
+            # every active rank holds its own subtrees + the whole top tree; non-owned
+            # subtree block columns are zero, so a sum assembles L once the
+            # (replicated) top tree is counted only from rank 0
+            owner = df.f.partition("owner")
+            bc_node = df.f.sym("bcol_node")
+            off, wdt, nrw = df.f.sym("bcol_off"), df.f.sym("bcol_width"), df.f.sym("bcol_nrow")
+            if rank != 0:
+                for b in np.where(owner[bc_node] < 0)[0]:
+                    L[int(off[b]):int(off[b]) + int(nrw[b]) * int(wdt[b])] = 0
+            dist.all_reduce(L, op=dist.ReduceOp.SUM, group=df.group)
+        if rank == 0:
+            Lh = L.cpu().numpy()
+            b = A @ np.ones(n)
+            x = _host_solve(df.f, Lh, b)
+            r = b - A @ x
+            check = {"resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
+                     "bwd_err": float(np.linalg.norm(r) /
+                                      (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
+    except Exception as e:  # the accuracy gate must never take the benchmark line down
+        check = {"error": repr(e)[:200]}
+    return check
 
 
 def _host_solve(f, L, b):
