@@ -62,7 +62,9 @@ def roofline_from_profile(f, val):
     """Dominant kernel = k_update<128> (fp64 MFMA GEMM with direct / scatter
     epilogue).  achieved = algorithmic flops of all its launches / the sum of
     their durations, measured with HIP events on the engine's own stream."""
-    ms = f.profile(val)
+    # two passes, per-launch minimum: a single pass occasionally shows one launch
+    # stalled by tens of ms (host/driver hiccup between its two event records)
+    ms = np.minimum(f.profile(val), f.profile(val))
     L = f.program("launches")
     kinds, tiles, flops = L[:, 0], L[:, 4], L[:, 5].astype(np.float64)
     sel = (kinds == 1) & (tiles == 128)
