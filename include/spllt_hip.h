@@ -93,10 +93,13 @@ int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
 int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_t capacity);
 
 /* engine knobs (before the first spllt_factor on this fkeep); flags: bit 0 =
- * replay through a hipGraph, bit 1 = single-stream program (no lookahead),
+ * reserved, bit 1 = single-stream program (no lookahead),
  * bit 2 = fused strip-TRSM kernel + tile-level lookahead on latency-bound levels
  * (experiment), bit 3 = with bit 2: keep per-panel launches for the diagonal tile
- * instead of the single-workgroup tile-chain kernel */
+ * instead of the single-workgroup tile-chain kernel, bit 4 = merge the update of
+ * block column c+1 by c into the left-looking panel updates of c+1 (experiment),
+ * bit 5 = fused TRSM + next-panel update launches (k_panel_step, experiment).
+ * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------

@@ -456,18 +456,17 @@ int64_t spllt_hip_sym_get(const void* akeep, const char* name, void* buf, int64_
   return -1;
 }
 
-int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int use_graph) {
+int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f) return SPLLT_ERROR_PARAMETER;
   if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
   if (panel_width > 0) f->eo.pw = std::min(panel_width, kPanelMax);
   if (tile > 0) f->eo.tile = tile;
-  f->eo.use_graph = (use_graph & 1) != 0;
-  f->eo.lookahead = (use_graph & 2) == 0;  // bit 1 set: single-stream program
-  f->eo.panel_step = (use_graph & 32) != 0;  // bit 5 set: fused TRSM + next-panel update launches (k_panel_step)
-  f->eo.lazy_next = (use_graph & 16) != 0;  // bit 4 set: c -> c+1 update merged into the panel updates of c+1
-  f->eo.fused_strip = (use_graph & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
-  f->eo.tile_chain = (use_graph & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
+  f->eo.lookahead = (flags & 2) == 0;  // bit 1 set: single-stream program
+  f->eo.panel_step = (flags & 32) != 0;  // bit 5 set: fused TRSM + next-panel update launches (k_panel_step)
+  f->eo.lazy_next = (flags & 16) != 0;  // bit 4 set: c -> c+1 update merged into the panel updates of c+1
+  f->eo.fused_strip = (flags & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
+  f->eo.tile_chain = (flags & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
   return 0;
 }
 

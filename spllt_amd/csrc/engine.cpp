@@ -12,7 +12,7 @@
 namespace spx {
 
 namespace {
-constexpr int kErrAlloc = -1, kErrHip = -30, kErrNotPosDef = -20;
+constexpr int kErrHip = -30, kErrNotPosDef = -20;
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -158,8 +158,6 @@ Engine::~Engine() {
   if (bulk_) hipStreamSynchronize(bulk_);
   for (auto& e : dag_events_) if (e) hipEventDestroy(e);
   if (bulk_) hipStreamDestroy(bulk_);
-  if (graph_exec_) hipGraphExecDestroy(graph_exec_);
-  if (graph_) hipGraphDestroy(graph_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
   hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_); hipFree(d_chain_); hipFree(d_panels_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);

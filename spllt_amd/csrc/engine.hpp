@@ -18,7 +18,6 @@ namespace spx {
 struct EngineOptions {
   int pw = 64;
   int tile = 128;
-  bool use_graph = false;  // capture the launch sequence into a hipGraph and replay it
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
   bool panel_step = false; // fused TRSM + next-panel update launches on latency-bound levels
   bool lazy_next = false;  // merge the c -> c+1 update into the panel updates of c+1
@@ -97,8 +96,6 @@ class Engine {
   int bulk_pad128_ = 0, bulk_pad64_ = 0;  // dynamic-LDS padding of bulk-stream launches (bytes)
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
-  hipGraph_t graph_ = nullptr;
-  hipGraphExec_t graph_exec_ = nullptr;
   bool pending_ = false;
   bool awaiting_exchange_ = false;
   int xchg_idx_ = -1;               // index of the L_EXCHANGE launch, -1 = single GPU

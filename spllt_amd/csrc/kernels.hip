@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   int seg = 0, kk = 0, klen = 0;
   const double* aptr = nullptr;
   const double* bptr = nullptr;
-  int64_t lda = 0, ldb = 0;
+  int64_t ldb = 0;
   auto seg_setup = [&](int sg) {
     const int bcol = u.src_bcol0 + sg;
     const int w = bc_w[bcol];
@@ -617,7 +617,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
     const int rshift = u.seg_r0 + sg * u.seg_stride;
     const int kbeg = (u.nseg == 1) ? u.k0 : 0;
     klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;
-    lda = w;
     aptr = L + base + (int64_t)(u.src_r0 + rowA - rshift) * w + kbeg + skof;
     if (u.mode == MODE_TRSM) {
       ldb = u.dinv_ld;
