@@ -344,26 +344,37 @@ int Engine::solve(double* x_host, int nrhs, int job) {
     HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
     HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
     HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");
-    HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * (size_t)std::max(1, S.n)), "hipMalloc(y)");
+    HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
     solve_ready_ = true;
   }
   const int n = S.n;
-  std::vector<double> yh((size_t)n);
-  for (int r = 0; r < nrhs; ++r) {
-    double* xr = x_host + (int64_t)r * n;
-    for (int i = 0; i < n; ++i) yh[S.order[i]] = xr[i];
-    HIPCHK(hipMemcpyAsync(d_y_, yh.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream_), "rhs H2D");
+  // up to four right-hand sides per sweep: every entry of L is read once for all of them
+  std::vector<double> yh((size_t)n * 4);
+  for (int done = 0; done < nrhs;) {
+    const int left = nrhs - done;
+    const int cur = left >= 4 ? 4 : (left >= 2 ? 2 : 1);   // kernel variants: 4, 2 or 1 per sweep
+    for (int q = 0; q < cur; ++q) {
+      const double* xr = x_host + (int64_t)(done + q) * n;
+      double* yq = yh.data() + (size_t)q * n;
+      for (int i = 0; i < n; ++i) yq[S.order[i]] = xr[i];
+    }
+    HIPCHK(hipMemcpyAsync(d_y_, yh.data(), sizeof(double) * (size_t)n * cur, hipMemcpyHostToDevice, stream_), "rhs H2D");
     auto run = [&](const std::vector<SolveLaunch>& ls) {
       for (const SolveLaunch& l : ls)
         launch_solve(stream_, l.kind, d_slist_, d_stiles_, l.first, l.count, d_sunits_, d_L_, d_dinv_,
-                     d_rlist_, d_y_);
+                     d_rlist_, d_y_, cur, (int64_t)n);
     };
     if (job == 0 || job == 1) run(sprog_.fwd);
     if (job == 0 || job == 2) run(sprog_.bwd);
     HIPCHK(hipGetLastError(), "solve launch");
-    HIPCHK(hipMemcpyAsync(yh.data(), d_y_, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream_), "x D2H");
+    HIPCHK(hipMemcpyAsync(yh.data(), d_y_, sizeof(double) * (size_t)n * cur, hipMemcpyDeviceToHost, stream_), "x D2H");
     HIPCHK(hipStreamSynchronize(stream_), "solve sync");
-    for (int i = 0; i < n; ++i) xr[i] = yh[S.order[i]];
+    for (int q = 0; q < cur; ++q) {
+      double* xr = x_host + (int64_t)(done + q) * n;
+      const double* yq = yh.data() + (size_t)q * n;
+      for (int i = 0; i < n; ++i) xr[i] = yq[S.order[i]];
+    }
+    done += cur;
   }
   return 0;
 }

@@ -941,25 +941,61 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+// 16 lanes per row: partial dot products of row[0..len) with NR vectors
+// x[q * XS + 0..len) for this lane's residues (k = sub, sub+16, ...), sixteen
+// independent loads in flight; every loaded entry of L serves all NR right-hand sides
+template <int NR, int XS>
+__device__ inline void dot16(const double* __restrict__ row, const double* x, int len, int sub,
+                             double (&out)[NR]) {
+#pragma unroll
+  for (int q = 0; q < NR; ++q) out[q] = 0.0;
+  for (int k0 = 0; k0 < len; k0 += 256) {
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = row[min(k0 + sub + 16 * e, len - 1)];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = k0 + sub + 16 * e;
+      const double a = k < len ? v[e] : 0.0;
+      const int kc = min(k, len - 1);
+#pragma unroll
+      for (int q = 0; q < NR; ++q) out[q] = __builtin_fma(a, x[q * XS + kc], out[q]);
+    }
+  }
+}
+__device__ inline double sum16(double v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+
+constexpr int kXS = 1024;  // LDS stride between right-hand sides (block column width <= 1024)
+
 // Solve with the diagonal tile of one block column per workgroup, using the
 // inverted 64x64 diagonal panels:  forward  x_p = inv(L_pp) (y_p - L_p,<p x_<p),
-// backward x_p = inv(L_pp)^T (y_p - L_>p,p^T x_>p).
-template <bool BWD>
+// backward x_p = inv(L_pp)^T (y_p - L_>p,p^T x_>p).  NR right-hand sides at once
+// (y[q * ldy + i]).
+template <bool BWD, int NR>
 __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list,
                                                     const SolveUnit* __restrict__ units,
                                                     const double* __restrict__ L,
                                                     const double* __restrict__ dinv,
                                                     const int* __restrict__ rlist,
-                                                    double* __restrict__ y) {
-  __shared__ double xb[1024];
-  __shared__ double tb[64];
-  __shared__ double part[4][64];
+                                                    double* __restrict__ y, int64_t ldy) {
+  __shared__ double xb[NR * kXS];
+  __shared__ double tb[NR * 64];
+  __shared__ double part[4][NR * 64];
   const SolveUnit u = units[list[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 15, rr = tid >> 4;   // 16 lanes per row, 16 rows per pass
   const int w = u.w, pw = u.pw;
   const double* A = L + u.off;
   const int* idx = rlist + u.idx_off;
-  for (int j = tid; j < w; j += 256) xb[j] = y[idx[j]];
+  for (int j = tid; j < w; j += 256) {
+    const int gi = idx[j];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) xb[q * kXS + j] = y[q * ldy + gi];
+  }
   __syncthreads();
   const int np = (w + pw - 1) / pw;
   for (int pp = 0; pp < np; ++pp) {
@@ -968,58 +1004,136 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
     int64_t slot = u.dinv_off + (int64_t)p * pw * pw;  // panels before p are full width
     const double* D = dinv + slot;
     if (!BWD) {
-      // t_j = y_j - sum_{k<c0} L[c0+j][k] x_k : one wave per row, lanes over k
-      for (int j = wave; j < pn; j += 4) {
-        const double* row = A + (int64_t)(c0 + j) * w;
-        double sacc = 0.0;
-        for (int k = lane; k < c0; k += 64) sacc += row[k] * xb[k];
-        sacc = wave_sum(sacc);
-        if (lane == 0) tb[j] = xb[c0 + j] - sacc;
+      // rows of inv(L_pp) for the second half, requested before the first half's loads
+      double dv[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dv[r][e] = D[(int64_t)min(rr + 16 * r, pn - 1) * pn + min(sub + 16 * e, pn - 1)];
+      // t_j = y_j - sum_{k<c0} L[c0+j][k] x_k
+      if (c0 > 0) {
+        double acc[4][NR];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dot16<NR, kXS>(A + (int64_t)(c0 + min(rr + 16 * r, pn - 1)) * w, xb, c0, sub, acc[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const double sacc = sum16(acc[r][q]);
+            const int j = rr + 16 * r;
+            if (sub == 0 && j < pn) tb[q * 64 + j] = xb[q * kXS + c0 + j] - sacc;
+          }
+      } else if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) tb[q * 64 + tid] = xb[q * kXS + tid];
       }
       __syncthreads();
-      // x_j = sum_{k<=j} Dinv[j][k] t_k
-      for (int j = wave; j < pn; j += 4) {
-        double sacc = (lane <= j && lane < pn) ? D[j * pn + lane] * tb[lane] : 0.0;
-        sacc = wave_sum(sacc);
-        if (lane == 0) xb[c0 + j] = sacc;
+      // x_j = sum_{k<=j} Dinv[j][k] t_k   (Dinv is lower triangular, zeros above)
+      {
+        double acc[4][NR];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            double sa = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = sub + 16 * e;
+              sa = __builtin_fma(k < pn ? dv[r][e] : 0.0, tb[q * 64 + min(k, pn - 1)], sa);
+            }
+            acc[r][q] = sa;
+          }
+        __syncthreads();   // every read of tb is done before xb/tb change
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const double sacc = sum16(acc[r][q]);
+            const int j = rr + 16 * r;
+            if (sub == 0 && j < pn) xb[q * kXS + c0 + j] = sacc;
+          }
       }
       __syncthreads();
     } else {
       // t_j = y_j - sum_{k>=c0+pn} L[k][c0+j] x_k : lane = column j, waves split k
       {
-        double sacc = 0.0;
-        if (lane < pn)
-          for (int k = c0 + pn + wave; k < w; k += 4) sacc += A[(int64_t)k * w + c0 + lane] * xb[k];
-        part[wave][lane] = sacc;
+        double sa[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) sa[q] = 0.0;
+        const int kbeg = c0 + pn, cj = c0 + min(lane, pn - 1);
+        for (int k0 = kbeg + wave; k0 < w; k0 += 32) {
+          double v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = A[(int64_t)min(k0 + 4 * e, w - 1) * w + cj];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = k0 + 4 * e;
+            const double a = k < w ? v[e] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, xb[q * kXS + min(k, w - 1)], sa[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) part[wave][q * 64 + lane] = sa[q];
       }
       __syncthreads();
-      if (tid < pn) tb[tid] = xb[c0 + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+      if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+          tb[q * 64 + tid] = xb[q * kXS + c0 + tid] - (part[0][q * 64 + tid] + part[1][q * 64 + tid] +
+                                                       part[2][q * 64 + tid] + part[3][q * 64 + tid]);
+      }
       __syncthreads();
       // x_j = sum_{k>=j} Dinv[k][j] t_k
       {
-        double sacc = 0.0;
-        if (lane < pn)
-          for (int k = lane + wave; k < pn; k += 4) sacc += D[k * pn + lane] * tb[k];
-        part[wave][lane] = sacc;
+        double sa[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) sa[q] = 0.0;
+        const int cj = min(lane, pn - 1);
+        for (int k0 = wave; k0 < pn; k0 += 32) {
+          double v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = D[min(k0 + 4 * e, pn - 1) * pn + cj];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = k0 + 4 * e;
+            const double a = k < pn ? v[e] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, tb[q * 64 + min(k, pn - 1)], sa[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) part[wave][q * 64 + lane] = sa[q];
       }
       __syncthreads();
-      if (tid < pn) xb[c0 + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+      if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+          xb[q * kXS + c0 + tid] = part[0][q * 64 + tid] + part[1][q * 64 + tid] +
+                                   part[2][q * 64 + tid] + part[3][q * 64 + tid];
+      }
       __syncthreads();
     }
   }
-  for (int j = tid; j < w; j += 256) y[idx[j]] = xb[j];
+  for (int j = tid; j < w; j += 256) {
+    const int gi = idx[j];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) y[q * ldy + gi] = xb[q * kXS + j];
+  }
 }
 
-// Rows below the diagonal tile, one strip of kSolveStripRows rows per workgroup.
+// Rows below the diagonal tile, one strip of kSolveStripRows (64) rows per workgroup.
 //   forward : y[idx[r]] -= sum_k L[r][k] x_k      (x = solved entries of this block column)
 //   backward: y[idx[k]] -= sum_r L[r][k] x[idx[r]]
-template <bool BWD>
+template <bool BWD, int NR>
 __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__ tiles,
                                                      const SolveUnit* __restrict__ units,
                                                      const double* __restrict__ L,
                                                      const int* __restrict__ rlist,
-                                                     double* __restrict__ y) {
-  __shared__ double xb[1024];
+                                                     double* __restrict__ y, int64_t ldy) {
+  __shared__ double xb[NR * kXS];
   const UpdTile tl = tiles[blockIdx.x];
   const SolveUnit u = units[tl.unit];
   const int tid = threadIdx.x;
@@ -1029,48 +1143,89 @@ __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__
   const double* A = L + u.off + (int64_t)r0 * w;
   const int* idx = rlist + u.idx_off;
   if (!BWD) {
-    for (int k = tid; k < w; k += 256) xb[k] = y[idx[k]];
-    __syncthreads();
-    // 16 lanes per row: coalesced 128-byte reads, 4-step reduction
-    const int sub = tid & 15, rr = tid >> 4;  // 16 rows per pass
-    for (int r = rr; r < nr; r += 16) {
-      const double* row = A + (int64_t)r * w;
-      double sacc = 0.0;
-      for (int k = sub; k < w; k += 16) sacc += row[k] * xb[k];
+    for (int k = tid; k < w; k += 256) {
+      const int gi = idx[k];
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
-      if (sub == 0) unsafeAtomicAdd(y + idx[r0 + r], -sacc);
+      for (int q = 0; q < NR; ++q) xb[q * kXS + k] = y[q * ldy + gi];
+    }
+    __syncthreads();
+    // 16 lanes per row (coalesced 128-byte reads), 4 rows per thread in flight
+    const int sub = tid & 15, rr = tid >> 4;
+    double acc[4][NR];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      dot16<NR, kXS>(A + (int64_t)min(rr + 16 * r, nr - 1) * w, xb, w, sub, acc[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rr + 16 * r;
+      const int gi = idx[r0 + min(row, nr - 1)];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const double sacc = sum16(acc[r][q]);
+        if (sub == 0 && row < nr) unsafeAtomicAdd(y + q * ldy + gi, -sacc);
+      }
     }
   } else {
-    for (int r = tid; r < nr; r += 256) xb[r] = y[idx[r0 + r]];
+    for (int r = tid; r < nr; r += 256) {
+      const int gi = idx[r0 + r];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) xb[q * kXS + r] = y[q * ldy + gi];
+    }
     __syncthreads();
     for (int k = tid; k < w; k += 256) {
-      double sacc = 0.0;
-      for (int r = 0; r < nr; ++r) sacc += A[(int64_t)r * w + k] * xb[r];
-      unsafeAtomicAdd(y + idx[k], -sacc);
+      double sa[NR];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) sa[q] = 0.0;
+      for (int q0 = 0; q0 < nr; q0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = A[(int64_t)min(q0 + e, nr - 1) * w + k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const double a = q0 + e < nr ? v[e] : 0.0;
+#pragma unroll
+          for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, xb[q * kXS + min(q0 + e, nr - 1)], sa[q]);
+        }
+      }
+      const int gi = idx[k];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) unsafeAtomicAdd(y + q * ldy + gi, -sa[q]);
     }
   }
 }
 
-void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
-                  int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y) {
-  if (count <= 0) return;
+template <int NR>
+static void launch_solve_nr(hipStream_t st, int kind, const int* list, const UpdTile* tiles,
+                            int64_t first, int64_t count, const SolveUnit* units, const double* L,
+                            const double* dinv, const int* rlist, double* y, int64_t ldy) {
   const dim3 g((unsigned)count), b(256);
   switch (kind) {
     case SV_DIAG_FWD:
-      hipLaunchKernelGGL(k_solve_diag<false>, g, b, 0, st, list + first, units, L, dinv, rlist, y);
+      hipLaunchKernelGGL((k_solve_diag<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
       break;
     case SV_DIAG_BWD:
-      hipLaunchKernelGGL(k_solve_diag<true>, g, b, 0, st, list + first, units, L, dinv, rlist, y);
+      hipLaunchKernelGGL((k_solve_diag<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
       break;
     case SV_STRIP_FWD:
-      hipLaunchKernelGGL(k_solve_strip<false>, g, b, 0, st, tiles + first, units, L, rlist, y);
+      hipLaunchKernelGGL((k_solve_strip<false, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy);
       break;
     default:
-      hipLaunchKernelGGL(k_solve_strip<true>, g, b, 0, st, tiles + first, units, L, rlist, y);
+      hipLaunchKernelGGL((k_solve_strip<true, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy);
       break;
   }
+}
+
+// nr = 1, 2 or 4 right-hand sides per sweep: y[q * ldy + i]
+void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
+                  int64_t count, const SolveUnit* units, const double* L, const double* dinv,
+                  const int* rlist, double* y, int nr, int64_t ldy) {
+  if (count <= 0) return;
+  if (nr >= 4)
+    launch_solve_nr<4>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
+  else if (nr >= 2)
+    launch_solve_nr<2>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
+  else
+    launch_solve_nr<1>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
 }
 
 // ---------------------------------------------------------------------------

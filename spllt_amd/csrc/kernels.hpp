@@ -36,7 +36,7 @@ void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
 // one launch of the device solve (kind = SolveKind)
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y);
+                  const int* rlist, double* y, int nr, int64_t ldy);
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
                           const int* col_list, int cls, int ndiag, const double* buffer);
 

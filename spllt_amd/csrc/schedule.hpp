@@ -182,7 +182,7 @@ struct SolveLaunch {
   int64_t first, count;  // DIAG: range in units; STRIP: range in tiles (unit, strip)
 };
 
-constexpr int kSolveStripRows = 256;
+constexpr int kSolveStripRows = 64;
 
 struct SolveProgram {
   std::vector<SolveUnit> units;   // one per block column, indexed by block column id

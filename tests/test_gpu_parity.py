@@ -366,11 +366,12 @@ def test_device_solve_jobs_and_multiple_rhs(gen, nb):
     f, val = make_case(A, nb=nb, nemin=16)
     f.factor(val).wait()
     rng = np.random.default_rng(0)
-    X = rng.standard_normal((f.n, 3))
+    X = rng.standard_normal((f.n, 7))     # 7 right-hand sides = sweeps of 4, 2 and 1
     B = A @ X
     got = f.solve(B)
-    for r in range(3):
+    for r in range(7):
         assert bwd_err(A, got[:, r], B[:, r]) <= 1e-14
+    np.testing.assert_allclose(f.solve(B[:, :3])[:, 2], got[:, 2], rtol=1e-12, atol=1e-12)
     y = f.solve(B[:, 0], job=1)
     x2 = f.solve(y, job=2)
     np.testing.assert_allclose(x2, got[:, 0], rtol=1e-12, atol=1e-12)
