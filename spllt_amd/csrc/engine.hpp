@@ -92,8 +92,11 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr;       // panel stream (stream 0 of the program)
   hipStream_t bulk_ = nullptr;         // bulk stream (stream 1)
-  int chain_prio_ = 0;                 // s_setprio for panel-stream update launches
-  int bulk_pad128_ = 0, bulk_pad64_ = 0;  // dynamic-LDS padding of bulk-stream launches (bytes)
+  int chain_prio_ = 1;                 // s_setprio for panel-stream update launches
+  // dynamic-LDS padding (bytes) of the trailing updates that run beside a panel chain:
+  // 64-tile launches (< 4096 large tiles, i.e. the chain is the bottleneck) are capped at
+  // 2 workgroups per CU so that chain kernels find free slots; large launches are not capped
+  int bulk_pad128_ = 0, bulk_pad64_ = 49152;
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
   bool pending_ = false;
