@@ -9,6 +9,6 @@ for cfg in "$@"; do
   python - "$cfg" $OUT/ab_$i.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print("%-60s ms %.3f  GF %.0f  u128 %.1f TF" % (sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["achieved"]), flush=True)
+print("%-60s ms %.3f  GF %.0f  roofline kernel %.1f TF" % (sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["achieved"]), flush=True)
 PY
 done
