@@ -377,3 +377,25 @@ def test_device_solve_jobs_and_multiple_rhs(gen, nb):
     np.testing.assert_allclose(x2, got[:, 0], rtol=1e-12, atol=1e-12)
     o, rc = oracle_factor(f, val)
     np.testing.assert_allclose(got[:, 1], o.solve(B[:, 1]), rtol=1e-10, atol=1e-11)
+
+
+def test_bench_workload_full_size_properties():
+    """BASELINE config 2 stand-in at its full size (n = 72 324, 755 GFLOP): the
+    factor agrees with the CPU oracle (MKL build), the reference's residual bar
+    holds (src/utils_mod.F90:462-467), a second factorization of the same values
+    reproduces L up to the order of the atomic adds, and chol(4A) = 2 chol(A)."""
+    A, order, cfg = matgen.build_config("nd24k_like", 1.0)
+    n, ptr, row, val = api.csc_lower_1based(A)
+    f = api.Factorization(n, ptr, row, nb=cfg["nb"], nemin=32, prune_tree=False, order=order)
+    L1 = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val, variant="mkl", nthreads=8)
+    assert rc == 0
+    mask = lower_mask(f)
+    assert rel_err(L1, o.arena(), mask) <= TOL_L
+    b = A @ np.ones(n)
+    x = f.solve(b)
+    assert bwd_err(A, x, b) <= 1e-14
+    L2 = f.factor(val).wait().get_factor()
+    assert np.abs(L2 - L1).max() <= 1e-13 * np.abs(L1).max()
+    L4 = f.factor(4.0 * val).wait().get_factor()
+    assert np.abs(L4 - 2.0 * L1).max() <= 1e-13 * np.abs(L1).max()
