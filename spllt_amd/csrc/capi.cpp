@@ -108,6 +108,26 @@ void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, c
   a->so.nemin = options->nemin;
   a->so.prune_tree = options->prune_tree != 0;
   a->so.ncpu = options->ncpu;
+  // The reference hands ptr/row to SSIDS unchecked (ssids_analyse(check = .false.),
+  // src/spllt_analyse_mod.F90:129): a malformed pattern is undefined behaviour there.
+  // Here it is a parameter error: column pointers must start at 1 and not decrease,
+  // rows must lie in the lower triangle (col <= row <= n) without duplicates.
+  {
+    bool ok = ptr[0] == 1;
+    for (int j = 0; ok && j < n; ++j) ok = ptr[j + 1] >= ptr[j];
+    std::vector<int> mark(ok ? (size_t)n : 0, -1);
+    for (int j = 0; ok && j < n; ++j)
+      for (int64_t e = (int64_t)ptr[j] - 1; ok && e < (int64_t)ptr[j + 1] - 1; ++e) {
+        const int r = row[e] - 1;
+        ok = r >= j && r < n && mark[r] != j;
+        if (ok) mark[r] = j;
+      }
+    if (!ok) {
+      std::fprintf(stderr, "spllt-hip: spllt_analyse: ptr/row is not a valid lower-triangular CSC pattern\n");
+      if (info) info->flag = SPLLT_ERROR_PARAMETER;
+      return;
+    }
+  }
   // 1-based int CSC -> 0-based
   std::vector<int64_t> p0((size_t)n + 1);
   for (int j = 0; j <= n; ++j) p0[j] = (int64_t)ptr[j] - 1;

@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from spllt_amd import _lib, api, matgen
 
@@ -81,3 +82,28 @@ def test_unknown_solve_job_is_rejected_like_reference():
     f.lib.spllt_solve(f.fkeep, C.byref(f.options), f.order.ctypes.data_as(C.POINTER(C.c_int)), 1,
                       x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(f.info), 6)
     assert f.info.flag == -10
+
+
+@pytest.mark.parametrize("name,ptr,row", [
+    ("row-out-of-range", [1, 3, 5, 6], [1, 2, 2, 9, 3]),
+    ("upper-triangle-entry", [1, 3, 5, 6], [1, 2, 1, 3, 3]),
+    ("decreasing-ptr", [1, 3, 2, 6], [1, 2, 2, 3, 3]),
+    ("duplicate-entry", [1, 4, 6, 7], [1, 2, 2, 2, 3, 3]),
+    ("ptr-not-starting-at-1", [0, 2, 4, 5], [1, 2, 2, 3, 3]),
+])
+def test_analyse_rejects_malformed_patterns(name, ptr, row):
+    """The reference passes ptr/row to SSIDS unchecked (undefined behaviour); the
+    drop-in reports SPLLT_ERROR_PARAMETER (-10) instead of touching bad memory."""
+    from spllt_amd import api
+    with pytest.raises(api.SplltError) as ei:
+        api.Factorization(3, np.array(ptr, dtype=np.int32), np.array(row, dtype=np.int32), nb=8)
+    assert ei.value.flag == -10
+
+
+def test_analyse_accepts_unsorted_rows_and_missing_diagonal():
+    from spllt_amd import api
+    f = api.Factorization(3, np.array([1, 4, 5, 6], dtype=np.int32),
+                          np.array([3, 1, 2, 2, 3], dtype=np.int32), nb=8)
+    assert f.sym_info()["nnz_l"] == 6
+    g = api.Factorization(3, np.array([1, 2, 3, 4], dtype=np.int32), np.array([2, 3, 3], dtype=np.int32), nb=8)
+    assert g.sym_info()["n"] == 3
