@@ -213,6 +213,8 @@ def main():
             roof["traffic_unit"] = ("bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
                                     "profiles/r01/pmc_summary.json)")
             roof["algorithmic_bytes_per_launch"] = round(k["algorithmic_bytes_per_launch"])
+            if "mfma_util_percent" in k:
+                roof["mfma_util_percent"] = round(k["mfma_util_percent"], 1)
     except (OSError, ValueError, KeyError):
         pass
     if args.profile_out:

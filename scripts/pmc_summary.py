@@ -2,7 +2,8 @@
 """Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc.sh for the roofline's
 `traffic` field.
 
-    python scripts/pmc_summary.py gpurun_out/pmc_<tag>_FETCH_SIZE gpurun_out/pmc_<tag>_WRITE_SIZE profiles/r01
+    python scripts/pmc_summary.py gpurun_out/pmc_<tag>_FETCH_SIZE gpurun_out/pmc_<tag>_WRITE_SIZE profiles/r01 \
+        [gpurun_out/pmc_<tag>_MFMA_BUSY gpurun_out/pmc_<tag>_MFMA_MOPS]
 
 HBM bytes per launch of each update kernel (k_update<128|64|32,...>) =
 (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 / launches: FETCH_SIZE is doubled as
@@ -68,8 +69,38 @@ def algorithmic_bytes(config="nd24k_like"):
     return out
 
 
+def mfma_by_kernel(dbusy, dmops):
+    """MFMA pipe utilisation and executed matrix flops per update kernel.
+    SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs; GRBM_GUI_ACTIVE comes back
+    summed over the 8 XCDs (checked against the kernel durations), so
+    util = busy / (gui_active / 8 * 1024 SIMDs).  MOPS_F64 * 512 = executed flops."""
+    res = {}
+    if dbusy:
+        f = glob.glob(os.path.join(dbusy, "**", "*counter_collection.csv"), recursive=True)[0]
+        t = pd.read_csv(f)
+        g = t.pivot_table(index=["Dispatch_Id", "Kernel_Name"], columns="Counter_Name",
+                          values="Counter_Value", aggfunc="sum").reset_index()
+        for T, kname in KERNELS.items():
+            sel = g[g["Kernel_Name"].str.contains(kname, regex=False)]
+            if len(sel):
+                busy, act = sel["SQ_VALU_MFMA_BUSY_CYCLES"].sum(), sel["GRBM_GUI_ACTIVE"].sum()
+                res.setdefault(kname, {})["mfma_util_percent"] = float(100 * busy / (act / 8 * 1024))
+    if dmops:
+        f = glob.glob(os.path.join(dmops, "**", "*counter_collection.csv"), recursive=True)[0]
+        t = pd.read_csv(f)
+        t = t[t["Counter_Name"] == "SQ_INSTS_VALU_MFMA_MOPS_F64"]
+        for T, kname in KERNELS.items():
+            sel = t[t["Kernel_Name"].str.contains(kname, regex=False)]
+            if len(sel):
+                res.setdefault(kname, {})["executed_mfma_flops_per_launch"] = float(
+                    sel["Counter_Value"].sum() * 512 / sel["Dispatch_Id"].nunique())
+    return res
+
+
 def main():
     dfetch, dwrite, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    dbusy = sys.argv[4] if len(sys.argv) > 4 else None
+    dmops = sys.argv[5] if len(sys.argv) > 5 else None
     per = {}
     for d, name in ((dfetch, "FETCH_SIZE"), (dwrite, "WRITE_SIZE")):
         g = counter_by_kernel(d, name)
@@ -95,6 +126,9 @@ def main():
                           "hbm_bytes_per_launch": (2 * per[kname]["FETCH_SIZE"]["avg_KB"] +
                                                    per[kname]["WRITE_SIZE"]["avg_KB"]) * 1024,
                           "pmc": per[kname]}
+    for kname, v in mfma_by_kernel(dbusy, dmops).items():
+        if kname in kernels:
+            kernels[kname].update(v)
     summary = {"workload": "nd24k_like", "kernels": kernels,
                "note": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 per launch: FETCH_SIZE doubled per "
                        "MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B; calibrated there for "
