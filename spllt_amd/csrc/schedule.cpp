@@ -18,6 +18,7 @@ static int64_t env_int(const char* name, int64_t dflt) {
 }
 
 struct Builder {
+  bool level_atomic = false;  // DIRECT units of the current level must use atomics
   const Symbolic& S;
   const ScheduleOptions& opt;
   Program& P;
@@ -82,6 +83,7 @@ struct Builder {
     const bool tiny_launch = n64 > 0 && n64 <= tiny_max;
     for (auto& u : us) {
       int uid = (int)P.units.size();
+      if (u.mode == MODE_DIRECT) u.atomic = level_atomic ? 1 : 0;
       P.units.push_back(u);
       int T = (u.mode == MODE_TRSM) ? (u.N > 64 ? 128 : pick_tile(u.M, u.N)) : pick_tile(u.M, u.N);
       if (small_launch && u.mode != MODE_TRSM) T = 64;
@@ -245,6 +247,8 @@ struct Builder {
         ps = worst <= opt.panel_step_limit;
       }
       const bool lazy = la && !fs && !ps && opt.lazy_next;
+      // merged / fused panel updates share destinations with concurrently running launches
+      level_atomic = lazy || ps;
       for (int c = 0; c < maxnc; ++c) {
         int maxp = 0;
         for (int s : nodes) {

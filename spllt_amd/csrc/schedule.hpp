@@ -50,7 +50,8 @@ struct UpdUnit {
   int lower;           // 1: write only entries with src_r0+i >= src_c0+j
   int b_bcol0;         // >= 0: B rows come from this block column (else same as A)
   int b_seg_r0;        // node-local row of the first stored row of B's segment 0
-  int pad_;
+  int atomic;          // DIRECT: 1 = subtract with atomics (another launch or unit may update the
+                       // same entries concurrently), 0 = plain read-modify-write (exclusive owner)
 };
 
 struct UpdTile {

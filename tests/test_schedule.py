@@ -172,9 +172,11 @@ def _access_sets(f):
                     W |= parts(db, int(u["d_row0"]), int(u["M"]))
                 elif u["mode"] == 1:
                     At |= {2 * db, 2 * db + 1}
-                else:
-                    # DIRECT updates subtract with L2 atomics (k_update epilogue)
+                elif u["atomic"]:
                     At |= parts(db, int(u["d_row0"]), int(u["M"]))
+                else:
+                    # plain read-modify-write: the launch must own the destination
+                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
         elif kind == 5:
             panels = f.program("panels")
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
