@@ -108,6 +108,7 @@ void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, c
   a->so.nemin = options->nemin;
   a->so.prune_tree = options->prune_tree != 0;
   a->so.ncpu = options->ncpu;
+  if (const char* e = std::getenv("SPLLT_HIP_RELAX")) a->so.relax = std::atof(e);  // experiment knob
   // The reference hands ptr/row to SSIDS unchecked (ssids_analyse(check = .false.),
   // src/spllt_analyse_mod.F90:129): a malformed pattern is undefined behaviour there.
   // Here it is a parameter error: column pointers must start at 1 and not decrease,
