@@ -320,8 +320,17 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
   int rc = do_wait(f);
   if (rc == 0 && !f->eng) rc = SPLLT_ERROR_PARAMETER;  // nothing factorized yet
   if (rc) { if (info) info->flag = rc; return; }
+  if (f->eo.nranks > 1) {
+    // A partitioned factor is spread over the ranks (own subtrees + replicated top
+    // tree); this process holds only its part, so a local substitution would be
+    // wrong.  Callers assemble L (spllt_hip_get_factor + a sum over the ranks, as
+    // spllt_amd/multigpu.py does for its accuracy gate) or solve on one GPU.
+    std::fprintf(stderr, "spllt-hip: spllt_solve on a partitioned (multi-GPU) factor is not implemented\n");
+    if (info) info->flag = SPLLT_ERROR_UNIMPLEMENTED;
+    return;
+  }
   static const bool host_solve_env = std::getenv("SPLLT_HIP_HOST_SOLVE") != nullptr;
-  if (host_solve_env || f->eo.nranks > 1) {
+  if (host_solve_env) {
     rc = ensure_hostL(f);
     if (rc) { if (info) info->flag = rc; return; }
     host_solve(*f->S, f->hostL.data(), nrhs, x, job);
