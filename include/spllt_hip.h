@@ -112,6 +112,19 @@ int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
  * reference src/spllt_factorization_mod.F90:39-191), calls spllt_hip_continue,
  * then spllt_wait/spllt_hip_wait.  The top tree is factorized on every rank. */
 int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange_elems);
+
+/* Substitution on DEVICE vectors in pivot order: y_dev holds nrhs vectors of
+ * length n, y[q*n + p(i)] = b_q[i], p = 0-based pivot position ("order" of spllt_hip_sym_get); overwritten by the solution in the same
+ * order.  job as spllt_solve (0 both sweeps, 1 forward, 2 backward; reference
+ * src/spllt_solve_mod.F90:203-221).  phase = -1: the whole solve (single GPU).
+ * On a partitioned factor the solve runs in three phases with the caller's
+ * exchange, like the factorization:
+ *   y = b on the entries this rank owns (own subtrees; rank 0 also the top tree), 0 elsewhere
+ *   phase 0 (forward, own subtrees)            -> all-reduce(sum) of y over the ranks
+ *   phase 1 (top tree, forward and backward), phase 2 (backward, own subtrees)
+ *   zero the entries this rank does not own    -> all-reduce(sum): x on every rank.
+ * spllt_solve itself returns SPLLT_ERROR_UNIMPLEMENTED on a partitioned factor. */
+int spllt_hip_solve_dev(void *fkeep, void *y_dev, int nrhs, int job, int phase);
 int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
 int spllt_hip_continue(void *fkeep);
 /* "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),

@@ -199,6 +199,14 @@ class Factorization:
             raise SplltError("spllt_solve", self.info.flag, self.last_error())
         return x
 
+    def solve_dev(self, y_dev_ptr, nrhs=1, job=0, phase=-1):
+        """spllt_hip_solve_dev: substitution on device vectors in pivot order
+        (y[q*n + p(i)] = b_q[i], p = 0-based pivot position ("order" of spllt_hip_sym_get)), in place; phase 0/1/2 on a partitioned factor."""
+        rc = self.lib.spllt_hip_solve_dev(self.fkeep, C.c_void_p(y_dev_ptr), nrhs, job, phase)
+        if rc < 0:
+            raise SplltError("spllt_hip_solve_dev", rc, self.last_error())
+        return self
+
     # ---- multi-GPU subtree partition ------------------------------------------
     def set_partition(self, rank, nranks):
         """Declare this process as `rank` of `nranks`; returns the number of

@@ -323,9 +323,10 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
   if (f->eo.nranks > 1) {
     // A partitioned factor is spread over the ranks (own subtrees + replicated top
     // tree); this process holds only its part, so a local substitution would be
-    // wrong.  Callers assemble L (spllt_hip_get_factor + a sum over the ranks, as
-    // spllt_amd/multigpu.py does for its accuracy gate) or solve on one GPU.
-    std::fprintf(stderr, "spllt-hip: spllt_solve on a partitioned (multi-GPU) factor is not implemented\n");
+    // wrong.  The partitioned solve is spllt_hip_solve_dev in three phases with the
+    // caller's all-reduce in between (spllt_amd/multigpu.py, DistributedFactorization.solve).
+    std::fprintf(stderr, "spllt-hip: spllt_solve on a partitioned (multi-GPU) factor needs the caller's "
+                         "exchange: use spllt_hip_solve_dev (phases 0, 1, 2)\n");
     if (info) info->flag = SPLLT_ERROR_UNIMPLEMENTED;
     return;
   }
@@ -339,6 +340,15 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
     if (rc) { if (info) info->flag = rc; return; }
   }
   fill_info(*f->S, info);
+}
+
+int spllt_hip_solve_dev(void* fkeep, void* y_dev, int nrhs, int job, int phase) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !y_dev) return SPLLT_ERROR_PARAMETER;
+  int rc = do_wait(f);
+  if (rc == 0 && !f->eng) rc = SPLLT_ERROR_PARAMETER;  // nothing factorized yet
+  if (rc) return rc;
+  return f->eng->solve_dev(static_cast<double*>(y_dev), nrhs, job, phase);
 }
 
 void spllt_solve_worker(void* fkeep, spllt_options_t* options, int* order, int nrhs, double* x,

@@ -334,41 +334,72 @@ int Engine::download(double* out, int64_t count) {
   return 0;
 }
 
+int Engine::prepare_solve() {
+  if (solve_ready_) return 0;
+  const Symbolic& S = *S_;
+  build_solve_program(S, prog_.pw, sprog_, opt_.nranks > 1 ? owner_.data() : nullptr, opt_.rank);
+  HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
+  HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
+  HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");
+  HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
+  solve_ready_ = true;
+  return 0;
+}
+
+// Substitution on device vectors in pivot order (y[q * n + p], q < nrhs), in place.
+// phase -1: everything that `job` asks for; 0/1/2: the three phases of a
+// partitioned solve (schedule.hpp, SolveProgram).
+int Engine::solve_dev(double* y_dev, int nrhs, int job, int phase) {
+  if (status_) return status_;
+  if (job < 0 || job > 2 || phase < -1 || phase > 2 || nrhs < 0 || !y_dev) return -10;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  int rc = prepare_solve();
+  if (rc) return rc;
+  const int n = S_->n;
+  const bool do_fwd = job == 0 || job == 1, do_bwd = job == 0 || job == 2;
+  for (int done = 0; done < nrhs;) {
+    const int left = nrhs - done;
+    const int cur = left >= 4 ? 4 : (left >= 2 ? 2 : 1);   // kernel variants: 4, 2 or 1 per sweep
+    double* y = y_dev + (int64_t)done * n;
+    auto run = [&](const std::vector<SolveLaunch>& ls, size_t a, size_t b) {
+      for (size_t i = a; i < b; ++i)
+        launch_solve(stream_, ls[i].kind, d_slist_, d_stiles_, ls[i].first, ls[i].count, d_sunits_, d_L_,
+                     d_dinv_, d_rlist_, y, cur, (int64_t)n);
+    };
+    const size_t nf = sprog_.fwd.size(), nb = sprog_.bwd.size();
+    if (do_fwd && (phase == -1 || phase == 0)) run(sprog_.fwd, 0, sprog_.fwd_nsub);
+    if (do_fwd && (phase == -1 || phase == 1)) run(sprog_.fwd, sprog_.fwd_nsub, nf);
+    if (do_bwd && (phase == -1 || phase == 1)) run(sprog_.bwd, 0, sprog_.bwd_ntop);
+    if (do_bwd && (phase == -1 || phase == 2)) run(sprog_.bwd, sprog_.bwd_ntop, nb);
+    done += cur;
+  }
+  HIPCHK(hipGetLastError(), "solve launch");
+  HIPCHK(hipStreamSynchronize(stream_), "solve sync");
+  return 0;
+}
+
 int Engine::solve(double* x_host, int nrhs, int job) {
   if (status_) return status_;
   if (job < 0 || job > 2) return -10;
   const Symbolic& S = *S_;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
-  if (!solve_ready_) {
-    build_solve_program(S, prog_.pw, sprog_);
-    HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
-    HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
-    HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");
-    HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
-    solve_ready_ = true;
-  }
+  int rc = prepare_solve();
+  if (rc) return rc;
   const int n = S.n;
   // up to four right-hand sides per sweep: every entry of L is read once for all of them
   std::vector<double> yh((size_t)n * 4);
   for (int done = 0; done < nrhs;) {
     const int left = nrhs - done;
-    const int cur = left >= 4 ? 4 : (left >= 2 ? 2 : 1);   // kernel variants: 4, 2 or 1 per sweep
+    const int cur = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
     for (int q = 0; q < cur; ++q) {
       const double* xr = x_host + (int64_t)(done + q) * n;
       double* yq = yh.data() + (size_t)q * n;
       for (int i = 0; i < n; ++i) yq[S.order[i]] = xr[i];
     }
     HIPCHK(hipMemcpyAsync(d_y_, yh.data(), sizeof(double) * (size_t)n * cur, hipMemcpyHostToDevice, stream_), "rhs H2D");
-    auto run = [&](const std::vector<SolveLaunch>& ls) {
-      for (const SolveLaunch& l : ls)
-        launch_solve(stream_, l.kind, d_slist_, d_stiles_, l.first, l.count, d_sunits_, d_L_, d_dinv_,
-                     d_rlist_, d_y_, cur, (int64_t)n);
-    };
-    if (job == 0 || job == 1) run(sprog_.fwd);
-    if (job == 0 || job == 2) run(sprog_.bwd);
-    HIPCHK(hipGetLastError(), "solve launch");
-    HIPCHK(hipMemcpyAsync(yh.data(), d_y_, sizeof(double) * (size_t)n * cur, hipMemcpyDeviceToHost, stream_), "x D2H");
-    HIPCHK(hipStreamSynchronize(stream_), "solve sync");
+    rc = solve_dev(d_y_, cur, job, -1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(yh.data(), d_y_, sizeof(double) * (size_t)n * cur, hipMemcpyDeviceToHost), "x D2H");
     for (int q = 0; q < cur; ++q) {
       double* xr = x_host + (int64_t)(done + q) * n;
       const double* yq = yh.data() + (size_t)q * n;

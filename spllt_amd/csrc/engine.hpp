@@ -68,6 +68,9 @@ class Engine {
   // spllt_solve on the device-resident factor (x: n x nrhs column-major, original
   // variable order, overwritten).  job 0 = both sweeps, 1 = forward, 2 = backward.
   int solve(double* x_host, int nrhs, int job);
+  // substitution on device vectors in pivot order; phase -1 = all, 0/1/2 = partitioned phases
+  int solve_dev(double* y_dev, int nrhs, int job, int phase);
+  int prepare_solve();
   double* device_L() { return d_L_; }
   hipStream_t stream() { return stream_; }
   const Program& program() const { return prog_; }

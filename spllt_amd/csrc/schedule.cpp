@@ -750,7 +750,7 @@ void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {
   b.run();
 }
 
-void build_solve_program(const Symbolic& S, int pw, SolveProgram& P) {
+void build_solve_program(const Symbolic& S, int pw, SolveProgram& P, const int* node_owner, int rank) {
   P = SolveProgram();
   pw = std::min(pw, kPanelMax);
   const int nn = S.nnodes, nbc = S.nbcol();
@@ -775,48 +775,63 @@ void build_solve_program(const Symbolic& S, int pw, SolveProgram& P) {
   }
   int maxlevel = -1;
   for (int s = 0; s < nn; ++s) maxlevel = std::max(maxlevel, S.level[s]);
-  std::vector<std::vector<int>> by_level(maxlevel + 1);
-  for (int s = 0; s < nn; ++s) by_level[S.level[s]].push_back(s);
   // one (diag, strip) launch pair per level and block-column step; the same
   // pairs are replayed in reverse for the backward substitution
   struct Step { int level; int64_t d0, dn, t0, tn; };
   std::vector<Step> steps;
-  for (int lev = 0; lev <= maxlevel; ++lev) {
-    const auto& nodes = by_level[lev];
-    int maxnc = 0;
-    for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
-    for (int c = 0; c < maxnc; ++c) {
-      Step st;
-      st.level = lev;
-      st.d0 = (int64_t)P.diag_list.size();
-      st.t0 = (int64_t)P.tiles.size();
-      for (int s : nodes) {
-        int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-        if (c >= nc) continue;
-        int b = S.node_bcol0[s] + c;
-        P.diag_list.push_back(b);
-        int below = S.bcols[b].nrow - S.bcols[b].width;
-        for (int t = 0; t * kSolveStripRows < below; ++t) {
-          UpdTile tt;
-          tt.unit = b;
-          tt.ti = (short)t;
-          tt.tj = 0;
-          P.tiles.push_back(tt);
-        }
-      }
-      st.dn = (int64_t)P.diag_list.size() - st.d0;
-      st.tn = (int64_t)P.tiles.size() - st.t0;
-      steps.push_back(st);
+  size_t nsub_steps = 0;
+  const int nphase = node_owner ? 2 : 1;
+  for (int ph = 0; ph < nphase; ++ph) {
+    std::vector<std::vector<int>> by_level(maxlevel + 1);
+    for (int s = 0; s < nn; ++s) {
+      bool take = true;
+      if (node_owner) take = (ph == 0) ? (node_owner[s] == rank) : (node_owner[s] < 0);
+      if (take) by_level[S.level[s]].push_back(s);
     }
+    for (int lev = 0; lev <= maxlevel; ++lev) {
+      const auto& nodes = by_level[lev];
+      int maxnc = 0;
+      for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
+      for (int c = 0; c < maxnc; ++c) {
+        Step st;
+        st.level = lev;
+        st.d0 = (int64_t)P.diag_list.size();
+        st.t0 = (int64_t)P.tiles.size();
+        for (int s : nodes) {
+          int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+          if (c >= nc) continue;
+          int b = S.node_bcol0[s] + c;
+          P.diag_list.push_back(b);
+          int below = S.bcols[b].nrow - S.bcols[b].width;
+          for (int t = 0; t * kSolveStripRows < below; ++t) {
+            UpdTile tt;
+            tt.unit = b;
+            tt.ti = (short)t;
+            tt.tj = 0;
+            P.tiles.push_back(tt);
+          }
+        }
+        st.dn = (int64_t)P.diag_list.size() - st.d0;
+        st.tn = (int64_t)P.tiles.size() - st.t0;
+        steps.push_back(st);
+      }
+    }
+    if (ph == 0) nsub_steps = steps.size();
   }
-  for (const Step& st : steps) {
+  for (size_t i = 0; i < steps.size(); ++i) {
+    const Step& st = steps[i];
     if (st.dn > 0) P.fwd.push_back(SolveLaunch{SV_DIAG_FWD, st.level, st.d0, st.dn});
     if (st.tn > 0) P.fwd.push_back(SolveLaunch{SV_STRIP_FWD, st.level, st.t0, st.tn});
+    if (i + 1 == nsub_steps) P.fwd_nsub = P.fwd.size();
   }
-  for (auto it = steps.rbegin(); it != steps.rend(); ++it) {
-    if (it->tn > 0) P.bwd.push_back(SolveLaunch{SV_STRIP_BWD, it->level, it->t0, it->tn});
-    if (it->dn > 0) P.bwd.push_back(SolveLaunch{SV_DIAG_BWD, it->level, it->d0, it->dn});
+  if (nsub_steps == 0) P.fwd_nsub = 0;
+  for (size_t i = steps.size(); i-- > 0;) {
+    const Step& st = steps[i];
+    if (i + 1 == nsub_steps) P.bwd_ntop = P.bwd.size();
+    if (st.tn > 0) P.bwd.push_back(SolveLaunch{SV_STRIP_BWD, st.level, st.t0, st.tn});
+    if (st.dn > 0) P.bwd.push_back(SolveLaunch{SV_DIAG_BWD, st.level, st.d0, st.dn});
   }
+  if (nsub_steps == 0) P.bwd_ntop = P.bwd.size();
 }
 
 }  // namespace spx

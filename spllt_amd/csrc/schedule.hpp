@@ -189,9 +189,17 @@ struct SolveProgram {
   std::vector<SolveUnit> units;   // one per block column, indexed by block column id
   std::vector<int> diag_list;     // unit ids in launch order (DIAG launches index this)
   std::vector<UpdTile> tiles;     // (unit, strip) pairs in launch order
+  // fwd = [own subtrees..., top tree...], bwd = its mirror [top tree..., own subtrees...].
+  // Without a partition everything counts as "own subtrees" (fwd_nsub = fwd.size(),
+  // bwd_ntop = 0).  A partitioned solve runs in three phases with an all-reduce of
+  // the right-hand side vector after the first and after the last:
+  //   0: fwd[0, fwd_nsub)   1: fwd[fwd_nsub, end) + bwd[0, bwd_ntop)   2: bwd[bwd_ntop, end)
   std::vector<SolveLaunch> fwd, bwd;
+  size_t fwd_nsub = 0, bwd_ntop = 0;
 };
 
-void build_solve_program(const Symbolic& S, int pw, SolveProgram& P);
+// node_owner (per node: owning rank, -1 = top tree) may be null: no partition
+void build_solve_program(const Symbolic& S, int pw, SolveProgram& P, const int* node_owner = nullptr,
+                         int rank = 0);
 
 }  // namespace spx

@@ -319,6 +319,39 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
                 mine[off[b]:off[b] + nr[b] * w[b]] = True
         assert rel_err(got, ref, mask & mine) <= TOL_L
         assert np.all(got[~mine] == 0.0)
+    # partitioned solve (spllt_hip_solve_dev phases 0/1/2, sums = the two all-reduces)
+    n = fs[0].n
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, 3))
+    B = A @ X
+    pos = fs[0].sym("order")          # 0-based pivot position of variable i
+    sptr = fs[0].sym("sptr")
+    own = owner[np.repeat(np.arange(len(sptr) - 1), np.diff(sptr))]
+    ys, masks = [], []
+    for r in range(world):
+        m = torch.tensor((own == r) | ((own < 0) & (r == 0)), device="cuda")
+        Y = np.zeros((3, n))
+        Y[:, pos] = B.T
+        y = torch.tensor(Y, device="cuda") * m
+        ys.append(y)
+        masks.append(m)
+    assert int(sum(m.sum().item() for m in masks)) == n      # every entry has exactly one owner
+    for f, y in zip(fs, ys):
+        f.solve_dev(y.data_ptr(), 3, 0, 0)
+    total = torch.stack(ys).sum(dim=0)
+    for y in ys:
+        y.copy_(total)
+    for f, y, m in zip(fs, ys, masks):
+        f.solve_dev(y.data_ptr(), 3, 0, 1)
+        f.solve_dev(y.data_ptr(), 3, 0, 2)
+        y *= m
+    got = torch.stack(ys).sum(dim=0).cpu().numpy()[:, pos].T
+    for q in range(3):
+        assert bwd_err(A, got[:, q], B[:, q]) <= 1e-14
+    np.testing.assert_allclose(got, X, rtol=0, atol=1e-9)
+    with pytest.raises(api.SplltError) as ei:      # spllt_solve needs the caller's exchange
+        fs[0].solve(B[:, 0])
+    assert ei.value.flag == -98
 
 
 def test_golden_vectors_gpu():
@@ -399,3 +432,26 @@ def test_bench_workload_full_size_properties():
     assert np.abs(L2 - L1).max() <= 1e-13 * np.abs(L1).max()
     L4 = f.factor(4.0 * val).wait().get_factor()
     assert np.abs(L4 - 2.0 * L1).max() <= 1e-13 * np.abs(L1).max()
+
+
+def test_solve_dev_on_device_vectors():
+    """spllt_hip_solve_dev: the substitution on caller-owned device vectors in
+    pivot order equals spllt_solve (5 right-hand sides, jobs 0 / 1 then 2)."""
+    torch = _torch()
+    A = matgen.nd_like((11, 10, 9), 2)
+    f, val = make_case(A, nb=64, nemin=16)
+    f.factor(val).wait()
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((f.n, 5))
+    B = A @ X
+    pos = f.sym("order")
+    Y = np.zeros((5, f.n))
+    Y[:, pos] = B.T
+    y = torch.tensor(Y, device="cuda")
+    f.solve_dev(y.data_ptr(), 5, 0, -1)
+    got = y.cpu().numpy()[:, pos].T
+    np.testing.assert_allclose(got, f.solve(B), rtol=1e-12, atol=1e-12)
+    y2 = torch.tensor(Y, device="cuda")
+    f.solve_dev(y2.data_ptr(), 5, 1, -1)
+    f.solve_dev(y2.data_ptr(), 5, 2, -1)
+    np.testing.assert_allclose(y2.cpu().numpy()[:, pos].T, got, rtol=1e-12, atol=1e-12)
