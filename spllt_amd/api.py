@@ -25,7 +25,7 @@ UPD_UNIT_DTYPE = np.dtype([
     ("src_r0", "<i4"), ("src_c0", "<i4"), ("M", "<i4"), ("N", "<i4"), ("k0", "<i4"),
     ("klen", "<i4"), ("d_ld", "<i4"), ("d_row0", "<i4"), ("d_col0", "<i4"), ("mode", "<i4"),
     ("dinv_ld", "<i4"), ("lower", "<i4"), ("b_bcol0", "<i4"), ("b_seg_r0", "<i4"),
-    ("atomic", "<i4"), ("pad2_", "<i4")])
+    ("atomic", "<i4"), ("a_w", "<i4"), ("a_off", "<i8")])
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
 STRIP_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("row0", "<i4"),
                              ("nrows", "<i4"), ("pw", "<i4")])

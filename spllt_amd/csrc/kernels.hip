@@ -612,8 +612,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   int64_t ldb = 0;
   auto seg_setup = [&](int sg) {
     const int bcol = u.src_bcol0 + sg;
-    const int w = bc_w[bcol];
-    const int64_t base = bc_off[bcol];
+    // segment 0 comes with the unit: one dependent lookup less before the first loads
+    const int w = sg == 0 ? u.a_w : bc_w[bcol];
+    const int64_t base = sg == 0 ? u.a_off : bc_off[bcol];
     const int rshift = u.seg_r0 + sg * u.seg_stride;
     const int kbeg = (u.nseg == 1) ? u.k0 : 0;
     klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;

@@ -50,6 +50,10 @@ struct OpsBatch {
       e = hipMalloc(d, std::max<size_t>(bytes, 8));
       if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
     };
+    for (UpdUnit& u : P.units) {  // segment 0 of every unit carries its block column
+      u.a_off = bc_off[(size_t)u.src_bcol0];
+      u.a_w = bc_w[(size_t)u.src_bcol0];
+    }
     up((void**)&d_off, bc_off.data(), bc_off.size() * sizeof(int64_t));
     up((void**)&d_w, bc_w.data(), bc_w.size() * sizeof(int));
     up((void**)&d_units, P.units.data(), P.units.size() * sizeof(UpdUnit));

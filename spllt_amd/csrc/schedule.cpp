@@ -84,6 +84,8 @@ struct Builder {
     for (auto& u : us) {
       int uid = (int)P.units.size();
       if (u.mode == MODE_DIRECT) u.atomic = level_atomic ? 1 : 0;
+      u.a_w = S.bcols[u.src_bcol0].width;
+      u.a_off = S.bcols[u.src_bcol0].off;
       P.units.push_back(u);
       int T = (u.mode == MODE_TRSM) ? (u.N > 64 ? 128 : pick_tile(u.M, u.N)) : pick_tile(u.M, u.N);
       if (small_launch && u.mode != MODE_TRSM) T = 64;

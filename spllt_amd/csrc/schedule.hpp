@@ -52,7 +52,10 @@ struct UpdUnit {
   int b_seg_r0;        // node-local row of the first stored row of B's segment 0
   int atomic;          // DIRECT: 1 = subtract with atomics (another launch or unit may update the
                        // same entries concurrently), 0 = plain read-modify-write (exclusive owner)
+  int a_w;             // width and arena offset of source block column src_bcol0 (segment 0):
+  int64_t a_off;       // saves the kernel one dependent table lookup before its first loads
 };
+static_assert(sizeof(UpdUnit) == 120, "UpdUnit layout (mirrored in spllt_amd/api.py)");
 
 struct UpdTile {
   int unit;
