@@ -98,7 +98,9 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * (experiment), bit 3 = with bit 2: keep per-panel launches for the diagonal tile
  * instead of the single-workgroup tile-chain kernel, bit 4 = merge the update of
  * block column c+1 by c into the left-looking panel updates of c+1 (experiment),
- * bit 5 = fused TRSM + next-panel update launches (k_panel_step, experiment).
+ * bit 5 = fused TRSM + next-panel update launches (k_panel_step, experiment),
+ * bit 6 = issue the inter-node updates only at the end of each level (default:
+ * in K slices on a third stream while the level's panel chains still run).
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
 

@@ -504,6 +504,7 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (tile > 0) f->eo.tile = tile;
   f->eo.lookahead = (flags & 2) == 0;  // bit 1 set: single-stream program
   f->eo.panel_step = (flags & 32) != 0;  // bit 5 set: fused TRSM + next-panel update launches (k_panel_step)
+  f->eo.slice_between = (flags & 64) == 0;  // bit 6 set: inter-node updates only at the end of a level
   f->eo.lazy_next = (flags & 16) != 0;  // bit 4 set: c -> c+1 update merged into the panel updates of c+1
   f->eo.fused_strip = (flags & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
   f->eo.tile_chain = (flags & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
@@ -623,6 +624,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.tile = f->eo.tile;
     so.lookahead = f->eo.lookahead;
     so.lazy_next = f->eo.lazy_next;
+    so.slice_between = f->eo.slice_between;
     so.panel_step = f->eo.panel_step;
     so.fused_strip = f->eo.fused_strip;
     so.tile_chain = f->eo.tile_chain;

@@ -58,6 +58,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.tile = opt_.tile;
   so.lookahead = opt_.lookahead;
   so.lazy_next = opt_.lazy_next;
+  so.slice_between = opt_.slice_between;
   so.panel_step = opt_.panel_step;
   so.fused_strip = opt_.fused_strip;
   so.tile_chain = opt_.tile_chain;
@@ -104,6 +105,7 @@ int Engine::upload() {
   } else {
     HIPCHK(hipStreamCreateWithPriority(&bulk_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
   }
+  HIPCHK(hipStreamCreateWithPriority(&far_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
   dag_events_.resize(prog_.nevents);
   for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
@@ -166,11 +168,12 @@ Engine::~Engine() {
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   if (ev_h2d_) hipEventDestroy(ev_h2d_);
+  if (far_) hipStreamDestroy(far_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
 int Engine::enqueue_launch(const Launch& l, bool serial) {
-  hipStream_t st = (serial || l.stream == 0) ? stream_ : bulk_;
+  hipStream_t st = (serial || l.stream == 0) ? stream_ : (l.stream == 2 ? far_ : bulk_);
   if (!serial) {
     if (l.wait0 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait0], 0), "stream wait");
     if (l.wait1 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait1], 0), "stream wait");
@@ -190,7 +193,7 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       const bool two = !serial && opt_.lookahead;
       const int prio = (two && l.stream == 0) ? chain_prio_ : 0;
       int pad = 0;
-      if (two && l.stream == 1 && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
+      if (two && l.stream >= 1 && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
                     d_relpos_, d_rlist_, d_dinv_, prio, pad);
     }

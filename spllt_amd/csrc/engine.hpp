@@ -20,6 +20,7 @@ struct EngineOptions {
   int tile = 128;
   bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
   bool panel_step = false; // fused TRSM + next-panel update launches on latency-bound levels
+  bool slice_between = true;  // inter-node updates in K slices beside the panel chains
   bool lazy_next = false;  // merge the c -> c+1 update into the panel updates of c+1
   bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
   bool tile_chain = true;   // (with fused_strip) single-workgroup panel chain per diagonal tile
@@ -95,6 +96,7 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr;       // panel stream (stream 0 of the program)
   hipStream_t bulk_ = nullptr;         // bulk stream (stream 1)
+  hipStream_t far_ = nullptr;          // far stream (stream 2): early inter-node update slices
   int chain_prio_ = 1;                 // s_setprio for panel-stream update launches
   // dynamic-LDS padding (bytes) of the trailing updates that run beside a panel chain:
   // 64-tile launches (< 4096 large tiles, i.e. the chain is the bottleneck) are capped at

@@ -1,5 +1,6 @@
 // Host-side construction of the batched stream-DAG program (see schedule.hpp).
 #include "schedule.hpp"
+#include <climits>
 #include <cstdlib>
 
 #include <algorithm>
@@ -151,6 +152,105 @@ struct Builder {
     us.clear();
   }
 
+  // Inter-node update units of node s, one per touched ancestor block column,
+  // covering every K segment (block column) of s.
+  void between_templates(int s, std::vector<UpdUnit>& out) {
+    const int nn = S.nnodes;
+    const int m = S.nrow(s);
+    const int* idx = S.rows(s);
+    int cptr = S.ncol(s);
+    int a = S.sparent[s];
+    while (a < nn && cptr < m) {
+      const int asa = S.sptr[a], aen = S.sptr[a + 1] - 1;
+      while (cptr < m && idx[cptr] < asa) cptr++;
+      if (cptr >= m) break;
+      if (idx[cptr] <= aen) {
+        // positions of rows cptr..m-1 of s inside a's row list
+        const int* aidx = S.rows(a);
+        const int am = S.nrow(a);
+        int64_t base = (int64_t)P.relpos.size();
+        {
+          int q = 0;
+          for (int r = cptr; r < m; ++r) {
+            while (q < am && aidx[q] < idx[r]) q++;
+            if (q >= am || aidx[q] != idx[r]) {
+              std::fprintf(stderr, "spllt-hip: structure inclusion violated (node %d -> %d)\n", s, a);
+              q = std::min(q, am - 1);
+            }
+            P.relpos.push_back(q);
+          }
+        }
+        const int first = cptr;
+        while (cptr < m && idx[cptr] <= aen) {
+          int cb = (idx[cptr] - asa) / nb;
+          int jlast = std::min(asa + (cb + 1) * nb - 1, aen);
+          int cptr2 = cptr;
+          while (cptr2 + 1 < m && idx[cptr2 + 1] <= jlast) cptr2++;
+          const BlockCol& D = S.bcols[S.node_bcol0[a] + cb];
+          UpdUnit u{};
+          u.b_bcol0 = -1;
+          u.lower = 1;
+          u.mode = MODE_SCATTER;
+          u.d_off = D.off;
+          u.d_ld = D.width;
+          u.d_row0 = D.r0;
+          u.d_col0 = asa + cb * nb;
+          u.relrow_off = base + (cptr - first);
+          u.gcol_off = S.rptr[s] + cptr;
+          u.src_bcol0 = S.node_bcol0[s];
+          u.nseg = S.node_bcol0[s + 1] - S.node_bcol0[s];
+          u.seg_r0 = 0;
+          u.seg_stride = nb;
+          u.src_r0 = cptr;
+          u.src_c0 = cptr;
+          u.M = m - cptr;
+          u.N = cptr2 - cptr + 1;
+          u.k0 = 0;
+          u.klen = -1;
+          out.push_back(u);
+          cptr = cptr2 + 1;
+        }
+      }
+      a = S.sparent[a];
+    }
+  }
+
+  // Units for the not yet issued K segments of every node of the level, given
+  // that its first `done` block columns are final.  final_pass: take everything
+  // that is left.  Otherwise a node contributes when it is complete, or when at
+  // least slice_width finished block columns are pending and two or more are
+  // still to come (every slice repeats the scatter of the whole update).
+  double collect_between(const std::vector<int>& nodes, const std::vector<std::vector<UpdUnit>>& tmpl,
+                         std::vector<int>& emitted, int done, bool final_pass,
+                         std::vector<UpdUnit>& out) {
+    double fl = 0;
+    static const int slice_w = (int)env_int("SPLLT_SLICE_WIDTH", opt.slice_width);
+    static const int slice_tail = (int)env_int("SPLLT_SLICE_TAIL", 2);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      const int s = nodes[i];
+      const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+      const int avail = std::min(done, nc);
+      int take = 0;
+      if (final_pass) take = nc - emitted[i];
+      else if (avail == nc) take = nc - emitted[i];
+      else if (avail - emitted[i] >= slice_w && nc - avail >= slice_tail) take = avail - emitted[i];
+      if (take <= 0 || tmpl[i].empty()) { if (take > 0) emitted[i] += take; continue; }
+      const int b0 = S.node_bcol0[s] + emitted[i];
+      int kcols = 0;
+      for (int b = b0; b < b0 + take; ++b) kcols += S.bcols[b].width;
+      for (const UpdUnit& t : tmpl[i]) {
+        UpdUnit u = t;
+        u.src_bcol0 = b0;
+        u.nseg = take;
+        u.seg_r0 = S.bcols[b0].r0;
+        out.push_back(u);
+        fl += 2.0 * kcols * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+      }
+      emitted[i] += take;
+    }
+    return fl;
+  }
+
   void run() {
     P.pw = pw;
     const int nn = S.nnodes;
@@ -248,6 +348,12 @@ struct Builder {
         }
         ps = worst <= opt.panel_step_limit;
       }
+      // inter-node update units of every node of the level (all K segments); they
+      // are issued in slices as the block columns they read become final
+      std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
+      std::vector<int> emitted(nodes.size(), 0);
+      for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
+      int evF_last = -1;            // last far-stream event (early inter-node slices)
       const bool lazy = la && !fs && !ps && opt.lazy_next;
       // merged / fused panel updates share destinations with concurrently running launches
       level_atomic = lazy || ps;
@@ -660,71 +766,32 @@ struct Builder {
           evB_prev = evB;
           evB1_prev = evB1;
           evB_hist.push_back(evB);
+          // (4b) early inter-node slices: block columns 0..c are final, so the part
+          // of update_between that reads them can run beside the remaining panel
+          // chains of the level (far stream) instead of after the last one
+          if (opt.slice_between && c + 1 < maxnc) {
+            std::vector<UpdUnit> sl;
+            double fs_ = collect_between(nodes, tmpl, emitted, c + 1, false, sl);
+            if (!sl.empty()) {
+              P.flops_between += fs_;
+              Edge ef;
+              ef.stream = 2;
+              ef.wait0 = evP;
+              static const int slice_pad = (int)env_int("SPLLT_SLICE_PAD", 0);
+              ef.overlap = slice_pad;
+              evF_last = P.nevents++;
+              ef.record = evF_last;
+              emit_gemm(lev, sl, fs_, true, ef);
+            }
+          }
         }
       }
 
-      // (5) inter-node updates of the whole level (update_between + scatter)
-      double fl = 0;
-      for (int s : nodes) {
-        const int m = S.nrow(s), ncol = S.ncol(s);
-        const int* idx = S.rows(s);
-        int cptr = ncol;
-        int a = S.sparent[s];
-        while (a < nn && cptr < m) {
-          const int asa = S.sptr[a], aen = S.sptr[a + 1] - 1;
-          while (cptr < m && idx[cptr] < asa) cptr++;
-          if (cptr >= m) break;
-          if (idx[cptr] <= aen) {
-            // positions of rows cptr..m-1 of s inside a's row list
-            const int* aidx = S.rows(a);
-            const int am = S.nrow(a);
-            int64_t base = (int64_t)P.relpos.size();
-            {
-              int q = 0;
-              for (int r = cptr; r < m; ++r) {
-                while (q < am && aidx[q] < idx[r]) q++;
-                if (q >= am || aidx[q] != idx[r]) {
-                  std::fprintf(stderr, "spllt-hip: structure inclusion violated (node %d -> %d)\n", s, a);
-                  q = std::min(q, am - 1);
-                }
-                P.relpos.push_back(q);
-              }
-            }
-            const int first = cptr;
-            while (cptr < m && idx[cptr] <= aen) {
-              int cb = (idx[cptr] - asa) / nb;
-              int jlast = std::min(asa + (cb + 1) * nb - 1, aen);
-              int cptr2 = cptr;
-              while (cptr2 + 1 < m && idx[cptr2 + 1] <= jlast) cptr2++;
-              const BlockCol& D = S.bcols[S.node_bcol0[a] + cb];
-              UpdUnit u{};
-            u.b_bcol0 = -1;
-            u.lower = 1;
-              u.mode = MODE_SCATTER;
-              u.d_off = D.off;
-              u.d_ld = D.width;
-              u.d_row0 = D.r0;
-              u.d_col0 = asa + cb * nb;
-              u.relrow_off = base + (cptr - first);
-              u.gcol_off = S.rptr[s] + cptr;
-              u.src_bcol0 = S.node_bcol0[s];
-              u.nseg = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              u.seg_r0 = 0;
-              u.seg_stride = nb;
-              u.src_r0 = cptr;
-              u.src_c0 = cptr;
-              u.M = m - cptr;
-              u.N = cptr2 - cptr + 1;
-              u.k0 = 0;
-              u.klen = -1;
-              us.push_back(u);
-              fl += 2.0 * ncol * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
-              cptr = cptr2 + 1;
-            }
-          }
-          a = S.sparent[a];
-        }
-      }
+      // (5) inter-node updates (update_between + scatter): whatever the slices
+      // issued during the panel chains have not covered yet
+      std::vector<UpdUnit> rest;
+      double fl = collect_between(nodes, tmpl, emitted, INT_MAX, true, rest);
+      us.insert(us.end(), rest.begin(), rest.end());
       P.flops_between += fl;
       if (!la) {
         emit_gemm(lev, us, fl);
@@ -734,6 +801,7 @@ struct Builder {
         Edge e;
         e.stream = 1;
         e.wait0 = evP_last;
+        e.wait1 = evF_last;   // early slices on the far stream
         ev_level = P.nevents++;
         e.record = ev_level;
         emit_gemm(lev, us, fl, true, e);

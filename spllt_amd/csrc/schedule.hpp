@@ -152,6 +152,8 @@ struct ScheduleOptions {
                           // into the left-looking update launches of block column c+1
   bool panel_step = false;  // fused TRSM + next-panel update launches (k_panel_step) on levels
   int panel_step_limit = 768;  // ... whose steps have at most this many 32-row tiles
+  bool slice_between = true;  // (lookahead) inter-node updates are issued in K slices on a third
+  int slice_width = 2;        // stream while the panel chains of the level are still running
   bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
   int strip_limit = 512;    // ... on levels whose steps have at most this many strips
   bool tile_chain = true;   // with fused_strip: the panel chain of a diagonal tile (w <= 256)

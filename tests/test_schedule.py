@@ -197,7 +197,8 @@ def _access_sets(f):
 
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
-                                        (lambda: matgen.poisson3d(9), 24, 8)])
+                                        (lambda: matgen.poisson3d(9), 24, 8),
+                                        (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8)])  # many block columns per node
 @pytest.mark.parametrize("flags", [0, 4, 12, 16, 32])
 def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     """Two-stream lookahead program: any two launches that touch the same block
@@ -259,5 +260,27 @@ def test_program_variants_agree(flags):
     assert ((L[:, 0] == 3).any()) == (flags in (4, 12))   # strip kernel needs the two-stream program
     # fused panel steps with bit 5 unless the strip mode (bit 2, two-stream only) is active
     assert ((L[:, 0] == 5).any()) == (bool(flags & 32) and not ((flags & 4) and not (flags & 2)))
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+@pytest.mark.parametrize("flags", [0, 64])
+def test_inter_node_updates_are_sliced_over_the_far_stream(flags):
+    """Default program: the inter-node update of a node is issued in K slices on
+    stream 2 while the level's panel chains still run (nodes that finish early
+    go completely); engine flag 64 keeps one launch per level.  Both reproduce
+    the oracle's factor when interpreted in numpy."""
+    A = matgen.nd_like((9, 8, 8), 2)
+    f, val = make_case(A, nb=8, nemin=8, panel_width=8, engine_flags=flags)
+    L = f.program("launches")
+    far = L[L[:, 6] == 2]
+    if flags == 0:
+        assert len(far) >= 4
+        units, tiles = f.program("units"), f.program("tiles")
+        nseg = [int(units[int(tiles[int(l[2])]["unit"])]["nseg"]) for l in far if l[3] > 0]
+        assert min(nseg) >= 1 and max(nseg) >= 2          # K slices of several block columns
+        assert all(units[int(tiles[int(l[2])]["unit"])]["mode"] == 1 for l in far if l[3] > 0)
+    else:
+        assert len(far) == 0
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
