@@ -855,9 +855,15 @@ __global__ __launch_bounds__(256) void k_trsm_strip(const UpdTile* __restrict__ 
       }
     }
     __syncthreads();
+    // a panel whose width is not a multiple of 16 ends inside a wave's tile: the
+    // columns beyond it belong to the next panel and must not be touched
+    const bool colok = wave * 16 + lr < pn;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
-      if (act) st_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane, acc[rt]);
+      if (act && colok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(rt * 16 + lq + 4 * r) * XLD + c0 + wave * 16 + lr] = acc[rt][r];
+      }
     // stage inv(L_pp), zero-padded to 64 x 64
     stage64(Ls, dinv + slot, pn, pn, pn, tid);
     __syncthreads();
@@ -878,7 +884,10 @@ __global__ __launch_bounds__(256) void k_trsm_strip(const UpdTile* __restrict__ 
     __syncthreads();                   // every wave has read the panel before it is overwritten
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
-      if (act) st_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane, res[rt]);
+      if (act && colok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(rt * 16 + lq + 4 * r) * XLD + c0 + wave * 16 + lr] = res[rt][r];
+      }
     slot += (int64_t)pn * pn;
   }
   __syncthreads();

@@ -371,7 +371,9 @@ struct Builder {
         };
         // (0) single-workgroup panel chain of the diagonal tiles (fused mode, w <= 256)
         bool chained = false;
-        if (fs && opt.tile_chain) {
+        // (k_tile_chain walks K in steps of 4 and 16-column tiles: panel widths that are
+        // no multiple of 16 keep the per-panel launches)
+        if (fs && opt.tile_chain && pw % 16 == 0) {
           bool all_fit = true;
           for (int s : nodes) {
             int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];

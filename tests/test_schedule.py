@@ -210,7 +210,8 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
     n = len(launches)
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert ((launches[:, 0] == 3).any()) == (flags in (4, 12)), "fused strip launches only with flag 4"
-    assert ((launches[:, 0] == 4).any()) == (flags == 4), "tile-chain launches with flag 4 (bit 3 disables)"
+    assert ((launches[:, 0] == 4).any()) == (flags == 4 and pw % 16 == 0), \
+        "tile-chain launches with flag 4 (bit 3 disables; panel widths that are no multiple of 16 too)"
     assert ((launches[:, 0] == 5).any()) == (flags == 32), "fused panel steps with bit 5 (not in strip mode)"
     rec_at = {}
     last_in_stream = {}
