@@ -67,3 +67,84 @@ def test_ragged_panels_in_every_engine_variant(flags, nb, pw):
     assert rel_err(got, o.arena(), lower_mask(f)) <= 1e-12
     b = A @ np.ones(f.n)
     assert bwd_err(A, f.solve(b), b) <= 1e-14
+
+
+def _partitioned_factor_and_solve(A, world, nb, nemin, pw):
+    """`world` rank-engines on this device; torch sums stand for the all-reduces."""
+    import torch
+    fs, bufs = [], []
+    for r in range(world):
+        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw)
+        xel = f.set_partition(r, world)
+        xb = torch.zeros(max(xel, 1), dtype=torch.float64, device="cuda")
+        f.set_exchange_buffer(xb.data_ptr())
+        fs.append(f)
+        bufs.append(xb)
+    dval = torch.tensor(val, device="cuda")
+    for f in fs:
+        f.factor_dev(dval.data_ptr())
+        f.wait()
+    total = torch.stack(bufs).sum(dim=0)
+    for xb in bufs:
+        xb.copy_(total)
+    torch.cuda.synchronize()
+    for f in fs:
+        f.continue_after_exchange()
+        f.wait()
+    n = fs[0].n
+    owner, sptr, pos = fs[0].partition("owner"), fs[0].sym("sptr"), fs[0].sym("order")
+    own = owner[np.repeat(np.arange(len(sptr) - 1), np.diff(sptr))]
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((n, 2))
+    B = A @ X
+    ys, masks = [], []
+    for r in range(world):
+        m = torch.tensor((own == r) | ((own < 0) & (r == 0)), device="cuda")
+        Y = np.zeros((2, n))
+        Y[:, pos] = B.T
+        ys.append(torch.tensor(Y, device="cuda") * m)
+        masks.append(m)
+    for f, y in zip(fs, ys):
+        f.solve_dev(y.data_ptr(), 2, 0, 0)
+    total = torch.stack(ys).sum(dim=0)
+    for y in ys:
+        y.copy_(total)
+    for f, y, m in zip(fs, ys, masks):
+        f.solve_dev(y.data_ptr(), 2, 0, 1)
+        f.solve_dev(y.data_ptr(), 2, 0, 2)
+        y *= m
+    got = torch.stack(ys).sum(dim=0).cpu().numpy()[:, pos].T
+    return fs, val, got, B
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_partitioned_factor_and_solve(seed):
+    """subtree partition over 2..5 ranks (some may own nothing, the top tree may be
+    one node) on random shapes: L of every rank against the oracle on the block
+    columns it holds, the partitioned solve against the residual bar"""
+    rng = np.random.default_rng(2000 + seed)
+    if seed % 3 == 0:
+        A = matgen.nd_like(tuple(int(x) for x in rng.integers(5, 11, size=3)), int(rng.integers(1, 3)))
+    elif seed % 3 == 1:
+        A = matgen.poisson2d(int(rng.integers(8, 40)))
+    else:
+        A = _random_spd(rng, int(rng.integers(40, 300)), float(rng.uniform(0.01, 0.1)))
+    world = int(rng.integers(2, 6))
+    nb = int(rng.choice([8, 16, 32, 48, 100]))
+    pw = int(rng.choice([8, 16, 24, 64]))
+    nemin = int(rng.choice([4, 16, 32]))
+    fs, val, got, B = _partitioned_factor_and_solve(A, world, nb, nemin, pw)
+    o, rc = oracle_factor(fs[0], val)
+    assert rc == 0
+    ref, mask = o.arena(), lower_mask(fs[0])
+    owner, bc_node = fs[0].partition("owner"), fs[0].sym("bcol_node")
+    off, w, nr = fs[0].sym("bcol_off"), fs[0].sym("bcol_width"), fs[0].sym("bcol_nrow")
+    for r, f in enumerate(fs):
+        L = f.get_factor()
+        mine = np.zeros_like(mask)
+        for b in range(len(off)):
+            if owner[bc_node[b]] in (r, -1):
+                mine[off[b]:off[b] + nr[b] * w[b]] = True
+        assert rel_err(L, ref, mask & mine) <= 1e-12, (world, nb, pw, nemin, r)
+    for q in range(2):
+        assert bwd_err(A, got[:, q], B[:, q]) <= 1e-14, (world, nb, pw, nemin)
