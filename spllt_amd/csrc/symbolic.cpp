@@ -231,20 +231,46 @@ void prune_tree(Symbolic& S, int nth) {
   }
 }
 
+// Proportional mapping of the assembly tree onto `nranks` ranks: a set of sibling
+// subtrees that shares a range of ranks is split into two groups whose weights
+// follow the split of the range; a group that reaches a single rank belongs to it
+// completely (its separators included, so whole branches stay rank-local); a node
+// whose subtree still spans several ranks is top tree (-1, replicated).  Compared
+// with dealing the pruned subtrees of spllt_prune_tree to ranks by weight alone
+// this keeps the top tree - replicated work and exchange volume - minimal.
 void assign_owners(const Symbolic& S, int nranks, std::vector<int>& owner) {
   const int nn = S.nnodes;
   owner.assign(nn, -1);
   if (nranks < 1) nranks = 1;
-  std::vector<int> roots;
-  for (int s = 0; s < nn; ++s)
-    if (S.small[s] == 1) roots.push_back(s);
-  std::stable_sort(roots.begin(), roots.end(),
-                   [&](int a, int b) { return S.weight[a] > S.weight[b]; });
-  std::vector<int64_t> load(nranks, 0);
-  for (int r : roots) {
-    int p = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    load[p] += S.weight[r];
-    for (int v = S.least_desc[r]; v <= r; ++v) owner[v] = p;
+  std::vector<std::vector<int>> kids(nn + 1);
+  for (int s = 0; s < nn; ++s) kids[std::min(S.sparent[s], nn)].push_back(s);
+  struct Job { std::vector<int> nodes; int r0, r1; };
+  std::vector<Job> stack;
+  stack.push_back(Job{kids[nn], 0, nranks});
+  while (!stack.empty()) {
+    Job j = std::move(stack.back());
+    stack.pop_back();
+    // a single node over several ranks is top tree: descend to its children
+    while (j.r1 - j.r0 > 1 && j.nodes.size() == 1 && !kids[j.nodes[0]].empty())
+      j.nodes = kids[j.nodes[0]];   // owner stays -1
+    if (j.nodes.empty()) continue;
+    if (j.r1 - j.r0 == 1 || j.nodes.size() == 1) {
+      for (int r : j.nodes)
+        for (int v = S.least_desc[r]; v <= r; ++v) owner[v] = j.r0;
+      continue;
+    }
+    std::stable_sort(j.nodes.begin(), j.nodes.end(),
+                     [&](int a, int b) { return S.weight[a] > S.weight[b]; });
+    const int rh = (j.r1 - j.r0) / 2;
+    const double tl = (double)rh, tr = (double)(j.r1 - j.r0 - rh);   // rank shares of the two groups
+    Job L{{}, j.r0, j.r0 + rh}, R{{}, j.r0 + rh, j.r1};
+    double wl = 0, wr = 0;
+    for (int r : j.nodes) {
+      if (wl / tl <= wr / tr) { L.nodes.push_back(r); wl += (double)S.weight[r]; }
+      else { R.nodes.push_back(r); wr += (double)S.weight[r]; }
+    }
+    stack.push_back(std::move(L));
+    stack.push_back(std::move(R));
   }
 }
 

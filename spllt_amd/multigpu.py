@@ -1,9 +1,12 @@
 """Multi-GPU factorization: one process per GPU, subtree partition, one RCCL
 exchange.
 
-Every rank analyses the same pattern with ``prune_tree=1, ncpu=world``
-(spllt_prune_tree restated, reference src/spllt_analyse_mod.F90:806-987), owns
-the pruned subtrees assigned to it, and accumulates its contributions to the
+Every rank analyses the same pattern and maps the assembly tree onto the ranks
+proportionally (symbolic.cpp, assign_owners: whole branches per rank, the nodes
+whose subtrees span several ranks form the replicated top tree - the role the
+pruning layer of spllt_prune_tree, reference src/spllt_analyse_mod.F90:806-987,
+plays for the reference's sequential subtrees), owns the branches assigned to it,
+and accumulates its contributions to the
 top tree in its own (zero-initialised) copy of the top-tree block columns.  The
 extend-add of the reference -- generated element + spllt_scatter_block
 (src/spllt_factorization_mod.F90:39-191, src/spllt_kernels_mod.F90:1122-1160)
@@ -174,10 +177,11 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
     flops = float(si_t[0].item()) if rank == 0 else 0.0
     check, own_w, top_flops = {}, np.zeros(max(w, 1)), 0.0
     if active and w > 1:
-        owner = df.f.partition("owner")
-        wgt, small = df.f.sym("weight"), df.f.sym("small")
-        for s in range(len(owner)):
-            if small[s] == 1:
+        # flops of the branches each rank owns = subtree weights of their roots
+        owner, wgt, par = df.f.partition("owner"), df.f.sym("weight"), df.f.sym("sparent")
+        nn = len(owner)
+        for s in range(nn):
+            if owner[s] >= 0 and (par[s] >= nn or owner[par[s]] < 0):
                 own_w[owner[s]] += wgt[s]
         top_flops = float(df.f.sym_info()["flops"]) - own_w.sum()
     if not args.no_check:
