@@ -51,6 +51,7 @@ for w in (1, 2, 4, 8):
     print(f"{cfg_name} width {w}: subtree phase max {max(tsub):.2f} ms (min {min(tsub):.2f}), "
           f"top tree {max(ttop) if ttop else 0.0:.2f} ms, exchange {xmb:.0f} MB, "
           f"sum without exchange {max(tsub) + (max(ttop) if ttop else 0.0):.2f} ms, F_sym {flops / 1e9:.0f} GF", flush=True)
+    print("   per rank: subtrees", [round(t, 2) for t in tsub], "top", [round(t, 2) for t in ttop], flush=True)
     for f in fs:
         f.close()
     del fs, bufs
