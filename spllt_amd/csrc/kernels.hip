@@ -1292,14 +1292,20 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
   // lds_pad: extra (unused) dynamic LDS that caps the workgroups per CU of a
   // trailing-update launch so that panel-chain kernels find room beside it
   const unsigned pad = lds_pad > 0 ? (unsigned)lds_pad : 0u;
-  static const bool attr_once = [] {
-    (void)hipFuncSetAttribute((const void*)k_update<128, 16, 4, 2>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_update<64, 16, 2, 2>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    return true;
-  }();
-  (void)attr_once;
+  if (pad > 0) {
+    // the padded launches exceed the default 64 KB of LDS per workgroup; the
+    // attribute is per device, so it is (re)applied for the current one
+    thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != attr_dev) {
+      (void)hipFuncSetAttribute((const void*)k_update<128, 16, 4, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_update<64, 16, 2, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      attr_dev = dev;
+    }
+  }
   if (tile == 128)
     hipLaunchKernelGGL((k_update<128, 16, 4, 2>), dim3((unsigned)count), dim3(512), pad, st, tiles,
                        units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
