@@ -33,6 +33,8 @@ PANEL_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("d_off", "<i8
                              ("ld", "<i4"), ("c0", "<i4"), ("pn", "<i4"), ("nrows", "<i4"),
                              ("d_ld", "<i4"), ("d_c0", "<i4"), ("d_pn", "<i4"), ("d_rshift", "<i4"),
                              ("s_ld", "<i4"), ("s_k", "<i4"), ("s_rshift", "<i4"), ("pad_", "<i4")])
+SOLVE_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("idx_off", "<i8"), ("w", "<i4"),
+                             ("nrow", "<i4"), ("pw", "<i4"), ("pad_", "<i4")])
 POTRF_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("n", "<i4"),
                              ("gcol", "<i4"), ("flags", "<i4")])
 
@@ -140,6 +142,16 @@ class Factorization:
             return raw.view(PANEL_UNIT_DTYPE)
         if name == "dinv_size":
             return int(raw.view(np.int64)[0])
+        if name == "solve_units":
+            return raw.view(SOLVE_UNIT_DTYPE)
+        if name == "solve_list":
+            return raw.view(np.int32)
+        if name == "solve_tiles":
+            return raw.view(UPD_TILE_DTYPE)
+        if name in ("solve_fwd", "solve_bwd"):
+            return raw.view(np.int64).reshape(-1, 4)
+        if name == "solve_split":
+            return raw.view(np.int64)
         return raw
 
     # ---- numerical phases --------------------------------------------------

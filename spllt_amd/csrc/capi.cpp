@@ -660,6 +660,28 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelStepUnit));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(PotrfUnit));
   if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
+  if (k.rfind("solve_", 0) == 0) {
+    // the substitution program (partition-aware like the factor program)
+    SolveProgram sp;
+    std::vector<int> owner;
+    if (f->eo.nranks > 1) assign_owners(*f->S, f->eo.nranks, owner);
+    build_solve_program(*f->S, f->eo.pw > 0 ? f->eo.pw : kPanelMax, sp,
+                        f->eo.nranks > 1 ? owner.data() : nullptr, f->eo.rank);
+    if (k == "solve_units") return raw(sp.units.data(), sp.units.size() * sizeof(SolveUnit));
+    if (k == "solve_list") return raw(sp.diag_list.data(), sp.diag_list.size() * sizeof(int));
+    if (k == "solve_tiles") return raw(sp.tiles.data(), sp.tiles.size() * sizeof(UpdTile));
+    if (k == "solve_fwd" || k == "solve_bwd") {
+      std::vector<int64_t> v;
+      for (const SolveLaunch& l : (k == "solve_fwd" ? sp.fwd : sp.bwd)) {
+        v.push_back(l.kind); v.push_back(l.level); v.push_back(l.first); v.push_back(l.count);
+      }
+      return raw(v.data(), v.size() * sizeof(int64_t));
+    }
+    if (k == "solve_split") {
+      int64_t v[2] = {(int64_t)sp.fwd_nsub, (int64_t)sp.bwd_ntop};
+      return raw(v, sizeof v);
+    }
+  }
   return -1;
 }
 

@@ -172,3 +172,46 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 else:
                     arena[idx[keep]] -= P[keep]
     return arena
+
+
+def emulate_solve(f, arena, y, job=0, phase=-1):
+    """Numpy interpreter of the substitution program (spllt_hip_program_get
+    "solve_*"): y is in pivot order, (nrhs, n), modified in place.  phase as
+    spllt_hip_solve_dev: -1 everything, 0/1/2 the phases of a partitioned solve."""
+    units, lst, tiles = f.program("solve_units"), f.program("solve_list"), f.program("solve_tiles")
+    fwd, bwd = f.program("solve_fwd"), f.program("solve_bwd")
+    nsub, ntop = (int(v) for v in f.program("solve_split"))
+    rlist = f.sym("rlist")
+    SR = 64  # kSolveStripRows
+
+    def blk(u):
+        w, nr, off = int(u["w"]), int(u["nrow"]), int(u["off"])
+        return arena[off:off + nr * w].reshape(nr, w), rlist[int(u["idx_off"]):int(u["idx_off"]) + nr], w
+
+    def run(launches):
+        for kind, _lev, first, count in launches:
+            if kind in (0, 3):       # DIAG forward / backward
+                for b in lst[first:first + count]:
+                    B, idx, w = blk(units[int(b)])
+                    Ld = np.tril(B[:w])
+                    y[:, idx[:w]] = sl.solve_triangular(Ld, y[:, idx[:w]].T, lower=True,
+                                                        trans="N" if kind == 0 else "T").T
+            else:                    # STRIP forward (1) / backward (2)
+                for t in tiles[first:first + count]:
+                    B, idx, w = blk(units[int(t["unit"])])
+                    r0 = w + int(t["ti"]) * SR
+                    r1 = min(r0 + SR, B.shape[0])
+                    if kind == 1:
+                        y[:, idx[r0:r1]] -= y[:, idx[:w]] @ B[r0:r1].T
+                    else:
+                        y[:, idx[:w]] -= y[:, idx[r0:r1]] @ B[r0:r1]
+    do_f, do_b = job in (0, 1), job in (0, 2)
+    if do_f and phase in (-1, 0):
+        run(fwd[:nsub])
+    if do_f and phase in (-1, 1):
+        run(fwd[nsub:])
+    if do_b and phase in (-1, 1):
+        run(bwd[:ntop])
+    if do_b and phase in (-1, 2):
+        run(bwd[ntop:])
+    return y
