@@ -146,8 +146,14 @@ double *spllt_hip_device_factor(void *fkeep);
 int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, double *h2d_ms,
                            int *launches);
 /* program export for tests: "launches" (int64 x 10 per launch: kind, level,
- * first, count, tile, flops, stream, wait0, wait1, record), "potrf" (PotrfUnit bytes), "units" (UpdUnit
- * bytes), "tiles" (UpdTile bytes), "strips" (StripUnit bytes), "relpos" (int32).  Returns byte length. */
+ * first, count, tile, flops, stream, wait0, wait1, record), "potrf" / "chains" (PotrfUnit bytes),
+ * "units" (UpdUnit bytes), "tiles" (UpdTile bytes), "strips" (StripUnit bytes), "panels"
+ * (PanelStepUnit bytes), "relpos" (int32), "dinv_size" (int64); the substitution program:
+ * "solve_units" (SolveUnit bytes), "solve_list" (int32), "solve_tiles" (UpdTile bytes),
+ * "solve_fwd" / "solve_bwd" (int64 x 4 per launch: kind, level, first, count), "solve_split"
+ * (int64 x 2: launches of fwd that belong to the own branches, launches of bwd that belong
+ * to the top tree).  Struct layouts: spllt_amd/csrc/schedule.hpp, mirrored as numpy dtypes in
+ * spllt_amd/api.py.  Returns the byte length. */
 int64_t spllt_hip_program_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 /* per-launch device time (ms) of one profiled factorization; returns #launches */
 int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int capacity);
