@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "engine.hpp"
-#include "hostsolve.hpp"
 #include "kernels.hpp"
 #include "spllt_hip.h"
 #include "symbolic.hpp"
@@ -315,8 +314,7 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
     if (info) info->flag = SPLLT_ERROR_PARAMETER;
     return;
   }
-  // Solve on the device-resident factor (no D2H of L).  SPLLT_HIP_HOST_SOLVE=1
-  // selects the host substitution instead (debugging aid).
+  // Solve on the device-resident factor (no D2H of L).
   int rc = do_wait(f);
   if (rc == 0 && !f->eng) rc = SPLLT_ERROR_PARAMETER;  // nothing factorized yet
   if (rc) { if (info) info->flag = rc; return; }
@@ -330,15 +328,8 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
     if (info) info->flag = SPLLT_ERROR_UNIMPLEMENTED;
     return;
   }
-  static const bool host_solve_env = std::getenv("SPLLT_HIP_HOST_SOLVE") != nullptr;
-  if (host_solve_env) {
-    rc = ensure_hostL(f);
-    if (rc) { if (info) info->flag = rc; return; }
-    host_solve(*f->S, f->hostL.data(), nrhs, x, job);
-  } else {
-    rc = f->eng->solve(x, nrhs, job);
-    if (rc) { if (info) info->flag = rc; return; }
-  }
+  rc = f->eng->solve(x, nrhs, job);
+  if (rc) { if (info) info->flag = rc; return; }
   fill_info(*f->S, info);
 }
 

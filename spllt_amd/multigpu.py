@@ -229,32 +229,3 @@ def _accuracy_gate(df, A, n, rank, w, active):
                                   (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x))),
                  "solve": "distributed (spllt_hip_solve_dev phases + 2 all-reduces of the rhs vector)"}
     return check
-
-
-def _host_solve(f, L, b):
-    """Forward/backward substitution with an assembled arena (numpy, test/bench
-    accuracy gate only)."""
-    order = f.sym("order")
-    sptr, rptr, rlist = f.sym("sptr"), f.sym("rptr"), f.sym("rlist")
-    nb0 = f.sym("node_bcol0")
-    off, w, r0, nr = f.sym("bcol_off"), f.sym("bcol_width"), f.sym("bcol_r0"), f.sym("bcol_nrow")
-    import scipy.linalg as sl
-    y = np.empty_like(b)
-    y[order] = b
-    nn = len(sptr) - 1
-    for s in range(nn):
-        rows = rlist[rptr[s]:rptr[s + 1]]
-        for bc in range(nb0[s], nb0[s + 1]):
-            blk = L[off[bc]:off[bc] + nr[bc] * w[bc]].reshape(nr[bc], w[bc])
-            idx = rows[r0[bc]:r0[bc] + nr[bc]]
-            d = sl.solve_triangular(blk[:w[bc]], y[idx[:w[bc]]], lower=True)
-            y[idx[:w[bc]]] = d
-            y[idx[w[bc]:]] -= blk[w[bc]:] @ d
-    for s in range(nn - 1, -1, -1):
-        rows = rlist[rptr[s]:rptr[s + 1]]
-        for bc in range(nb0[s + 1] - 1, nb0[s] - 1, -1):
-            blk = L[off[bc]:off[bc] + nr[bc] * w[bc]].reshape(nr[bc], w[bc])
-            idx = rows[r0[bc]:r0[bc] + nr[bc]]
-            rhs = y[idx[:w[bc]]] - blk[w[bc]:].T @ y[idx[w[bc]:]]
-            y[idx[:w[bc]]] = sl.solve_triangular(blk[:w[bc]], rhs, lower=True, trans="T")
-    return y[order]
