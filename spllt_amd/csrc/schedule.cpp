@@ -68,10 +68,11 @@ struct Builder {
       return;
     }
     std::vector<UpdTile> t128, t64, t32;
-    // Latency-bound phases (a handful of tiles: one 128-tile with K = 256 is
-    // ~60 us of dependent MFMAs on one CU) are cut into smaller tiles so that
-    // more CUs share the work: 64-tiles below 64 large tiles, 32-tiles when
-    // even those would leave most of the chip idle.
+    // Tile size per launch (measured, scripts/update_bench.hip + gpu_tilesweep.sh):
+    // the 128-tile (8 waves, 2 workgroups/CU) only pays when the launch fills the
+    // chip for many rounds (>= 4096 tiles); the 64-tile is as fast per flop at every
+    // K and has the shorter tail; latency-bound launches (<= 2048 64-tiles: one
+    // round) use 32-tiles so that every CU gets work and a lone tile takes ~10 us.
     int64_t n128 = 0, n64 = 0;
     for (auto& u : us) {
       if (u.mode == MODE_TRSM) continue;
