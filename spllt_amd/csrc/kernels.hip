@@ -610,11 +610,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   const double* aptr = nullptr;
   const double* bptr = nullptr;
   int64_t ldb = 0;
+  // width / offset of the NEXT K segment, requested one segment ahead so that a
+  // segment switch does not stall on two dependent table loads
+  int nxt_w = 0;
+  int64_t nxt_off = 0;
   auto seg_setup = [&](int sg) {
     const int bcol = u.src_bcol0 + sg;
     // segment 0 comes with the unit: one dependent lookup less before the first loads
-    const int w = sg == 0 ? u.a_w : bc_w[bcol];
-    const int64_t base = sg == 0 ? u.a_off : bc_off[bcol];
+    const int w = sg == 0 ? u.a_w : nxt_w;
+    const int64_t base = sg == 0 ? u.a_off : nxt_off;
+    if (sg + 1 < u.nseg) {
+      nxt_w = bc_w[bcol + 1];
+      nxt_off = bc_off[bcol + 1];
+    }
     const int rshift = u.seg_r0 + sg * u.seg_stride;
     const int kbeg = (u.nseg == 1) ? u.k0 : 0;
     klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;
