@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     u.d_off = src_elems; u.src_bcol0 = 0; u.nseg = 1; u.seg_r0 = 0; u.seg_stride = K;
     u.src_r0 = N; u.src_c0 = 0; u.M = M; u.N = N; u.k0 = 0; u.klen = -1; u.d_ld = N;
     u.d_row0 = 0; u.d_col0 = 0; u.mode = MODE_DIRECT; u.lower = 0; u.b_bcol0 = -1;
+    u.a_off = 0; u.a_w = K;   // block column of segment 0 (carried by the unit)
     UpdUnit* du;
     hipMalloc(&du, sizeof(u));
     hipMemcpy(du, &u, sizeof(u), hipMemcpyHostToDevice);

@@ -576,7 +576,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   // latency-critical launches (panel chain) outrank the trailing-update waves
   // they share a SIMD with
   if (prio) __builtin_amdgcn_s_setprio(3);
-  constexpr int LDK = BK + 2;         // 2*odd doubles: conflict-free ds_read_b64 (see above)
+  // LDS row stride BK + 3 doubles (odd): measured best (scripts/update_bench.hip with
+  // -DUPD_LDK_PAD=n).  BK + 2 makes the MFMA operand reads conflict-free but the staging
+  // writes collide (SQ_LDS_BANK_CONFLICT = 40 % of the LDS-active cycles); the odd
+  // strides trade a few read conflicts for conflict-free writes: 32-tile +12 % at
+  // K = 1024, 64-tile +1 %, whole factorization -0.7 %.
+#ifndef UPD_LDK_PAD
+#define UPD_LDK_PAD 3
+#endif
+  constexpr int LDK = BK + UPD_LDK_PAD;
   constexpr int NT = 64 * WM * WN;    // threads: WM x WN waves
   constexpr int FMM = T / WM / 16;    // MFMA fragments per wave, rows
   constexpr int FMN = T / WN / 16;    // MFMA fragments per wave, columns
