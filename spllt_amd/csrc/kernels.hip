@@ -843,6 +843,14 @@ __global__ __launch_bounds__(256) void k_trsm_strip(const UpdTile* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 16; ++e) Xs[si * XLD + c + e] = (si < nr && c + e < w) ? v[e] : 0.0;
     }
+    // A ragged last panel makes the 16-wide accumulator tiles and the K loop (steps of
+    // 4) read up to 63 columns past the block column.  Those operands meet zero
+    // factors, but stale LDS may hold NaN bit patterns and 0 * NaN poisons the whole
+    // output row (seen once as a spurious "not positive definite"): clear them.
+    for (int c = wpad + sc; c < min(wpad + 64, XLD); c += TPR * 16)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (c + e < XLD) Xs[si * XLD + c + e] = 0.0;
   }
   const int np = (w + pw - 1) / pw;
   int64_t slot = u.dinv_off;
