@@ -98,6 +98,12 @@ void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, c
     if (info) info->flag = SPLLT_ERROR_PARAMETER;
     return;
   }
+  if (options->nb > 1024) {
+    // the substitution kernels keep one block column's worth of the right-hand side in LDS
+    std::fprintf(stderr, "spllt-hip: spllt_analyse: nb = %d is not supported (nb <= 1024)\n", options->nb);
+    if (info) info->flag = SPLLT_ERROR_UNIMPLEMENTED;
+    return;
+  }
   Akeep* a = static_cast<Akeep*>(*akeep);
   Fkeep* f = static_cast<Fkeep*>(*fkeep);
   if (!a) { a = new (std::nothrow) Akeep(); *akeep = a; }

@@ -107,3 +107,12 @@ def test_analyse_accepts_unsorted_rows_and_missing_diagonal():
     assert f.sym_info()["nnz_l"] == 6
     g = api.Factorization(3, np.array([1, 2, 3, 4], dtype=np.int32), np.array([2, 3, 3], dtype=np.int32), nb=8)
     assert g.sym_info()["n"] == 3
+
+
+def test_analyse_rejects_tile_sizes_beyond_the_kernel_limit():
+    from spllt_amd import api
+    ptr, row = np.array([1, 3, 5, 6], dtype=np.int32), np.array([1, 2, 2, 3, 3], dtype=np.int32)
+    with pytest.raises(api.SplltError) as ei:
+        api.Factorization(3, ptr, row, nb=2048)
+    assert ei.value.flag == -98
+    assert api.Factorization(3, ptr, row, nb=1024).sym_info()["n"] == 3

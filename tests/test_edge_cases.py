@@ -38,6 +38,10 @@ EDGE = [
      dict(nb=64, nemin=4, panel_width=48)),
     ("nb-larger-than-n", lambda: matgen.poisson2d(7), dict(nb=1000, nemin=64)),
 ]
+# the widest supported block column (nb = 1024) with a ragged second one; GPU only (the numpy
+# interpreter would take a while on 1100^3)
+EDGE_GPU = EDGE + [("dense1100-nb1024", lambda: sp.csc_matrix(np.ones((1100, 1100)) + 1100 * np.eye(1100)),
+                    dict(nb=1024, nemin=4))]
 
 
 @pytest.mark.parametrize("name,gen,kw", EDGE, ids=[e[0] for e in EDGE])
@@ -57,7 +61,7 @@ def test_empty_matrix_is_accepted():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,gen,kw", EDGE, ids=[e[0] for e in EDGE])
+@pytest.mark.parametrize("name,gen,kw", EDGE_GPU, ids=[e[0] for e in EDGE_GPU])
 def test_edge_case_factor_and_solve_on_gpu(name, gen, kw):
     A = gen()
     f, val = make_case(A, **kw)
