@@ -147,40 +147,34 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
     if forced:
         widths = [min(max(forced, 1), world)]
     dval = torch.tensor(val, device="cuda")
-    trial = {}
-    best_w, best_t, best = None, None, None
+    trial, groups = {}, {}
+    best_w, best_t = None, None
     for w in widths:
-        group = dist.new_group(ranks=list(range(w))) if 1 < w < world else None
+        # every width is tried alone on the device: engines that share the heap with
+        # others can land on fragmented memory and run 2x slower, which would bias
+        # the comparison
+        groups[w] = dist.new_group(ranks=list(range(w))) if 1 < w < world else None
         active = rank < w
         df = None
         if active:
             df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
-                                          panel_width=args.panel, group=group)
+                                          panel_width=args.panel, group=groups[w])
         _timed(df, dval, 1, active)                      # first touch
         t = _timed(df, dval, max(1, args.warmup), active) / max(1, args.warmup)
         trial[w] = round(t * 1e3, 3)
         if best_t is None or t < best_t:
-            if best is not None:
-                best.close()
-            best_w, best_t, best = w, t, df
-        elif df is not None:
+            best_w, best_t = w, t
+        if df is not None and len(widths) > 1:
             df.close()
+            df = None
+            torch.cuda.empty_cache()
     w = best_w
     active = rank < w
-    df = best
     if len(widths) > 1:
-        # rebuild the chosen configuration on a clean device heap: an engine created while
-        # others were alive can land on fragmented memory (seen as a 2.3x slower engine when
-        # eight of them shared one device)
-        group = None
-        if df is not None:
-            group = df.group
-            df.close()
-        torch.cuda.empty_cache()
         df = None
         if active:
             df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
-                                          panel_width=args.panel, group=group)
+                                          panel_width=args.panel, group=groups[w])
         _timed(df, dval, 1, active)
     t_total = _timed(df, dval, args.steps, active)
     si_t = torch.zeros(4, dtype=torch.float64, device="cuda")
