@@ -9,6 +9,11 @@
 //                   (:2108-2237, :2010-2053) with the scatter fused into the
 //                   GEMM epilogue -- one fp64-MFMA kernel, three epilogues.
 //   k_scatter_block a26 spllt_scatter_block (:1122-1160) extend-add
+//   k_solve_diag / k_solve_strip   forward / backward substitution on the device-resident
+//                   factor (reference src/spllt_solve_mod.F90), up to 4 right-hand sides
+//   experimental variants of the panel chain (not in the default program, kept with
+//   their tests because the measurements in DESIGN.md refer to them):
+//   k_trsm_strip (flag 4), k_tile_chain (flag 4), k_panel_step (flag 32)
 //
 // Storage convention: every block column of L is a
 // row-major (rows x width) matrix; all products are C = A * B^T with both
@@ -45,8 +50,9 @@ __global__ __launch_bounds__(256) void k_scatter_val(double* __restrict__ L,
 //   * off-diagonal work (block-column updates, panel solves through the
 //     inverted 16x16 diagonal blocks, and the block recurrences of the inverse)
 //     runs on v_mfma_f64_16x16x4_f64, one sub-block per wavefront;
-//   * the 16x16 diagonal blocks are factored and inverted in registers by one
-//     wavefront (lane i owns row i, columns/rows exchanged with ds_bpermute).
+//   * the 16x16 diagonal blocks are factored AND inverted in registers by one
+//     wavefront in the same loop (lane i owns row i of D and column i of inv(D);
+//     the pivot column is broadcast with v_readlane, 1/sqrt from v_rsq_f64 + Newton).
 // An accumulator tile S (C layout: reg r = row (l>>4)+4r, col l&15) is exactly
 // the B operand of k-step r, so X_IJ = -inv(D_I) * S needs no data movement.
 // A non-positive pivot records (pivot column + 1) in *flag (smallest wins).
