@@ -260,7 +260,8 @@ def main():
         "detail": {"device_ms_per_step": round(float(np.mean(dev_ms)), 3), "analyse_s": round(t_analyse, 2),
                    "dropin_factor_s": round(t_h2d, 4), "L_d2h_s": round(t_d2h, 4),
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
-                   "launches": f.times()["launches"], "kernel_table": table, "check": check},
+                   "launches": f.times()["launches"], "kernel_table": table, "check": check,
+                   "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin},
     }
     print(json.dumps(out))
 
