@@ -97,15 +97,21 @@ class DistributedFactorization:
         Y[:, pos] = B.T
         y = torch.tensor(Y, device="cuda")             # y[q, p]: pivot order, rhs-major
         y *= mask
+        # The engine launches on its own (non-blocking) HIP stream and solve_dev only
+        # synchronises that one; torch's elementwise ops and the RCCL all-reduce run on
+        # torch's streams.  Every hand-over between the two is a full device sync.
+        torch.cuda.synchronize()
         if self.world == 1:
             self.f.solve_dev(y.data_ptr(), nrhs, 0, -1)
         else:
             self.f.solve_dev(y.data_ptr(), nrhs, 0, 0)
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize()
             self.f.solve_dev(y.data_ptr(), nrhs, 0, 1)
             self.f.solve_dev(y.data_ptr(), nrhs, 0, 2)
             y *= mask
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize()
         X = y.cpu().numpy()[:, pos].T
         return X[:, 0].copy() if one else np.asfortranarray(X)
 

@@ -63,6 +63,41 @@ def test_factor_matches_oracle(name, gen, nb, nemin, pw):
     f.close()
 
 
+# BASELINE configs 3/4/5 at their tile sizes with supernodes that really span several block
+# columns of full width and several full-height tiles (reference kernels_mod:1261-1292,
+# :2108-2237: update_block / update_between across block columns, K-segment walk).
+BIG_CASES = [
+    ("p3d40-nb384", lambda: matgen.poisson3d(40), 384),          # config 3 tile size
+    ("fe27-16-nb512", lambda: matgen.fe27((16, 16, 16), 3), 512),  # config 4 tile size / pattern
+    ("fe27-18-nb768", lambda: matgen.fe27((18, 18, 18), 3), 768),  # config 5 tile size / pattern
+]
+
+
+def _assert_multicolumn(f, nb):
+    """the case must not degenerate: some block column is taller than two tiles
+    and some supernode has at least three block columns"""
+    assert int(f.sym("bcol_nrow").max()) > 2 * nb
+    assert int(np.diff(f.sym("node_bcol0")).max()) >= 3
+    assert int(f.sym("bcol_width").max()) == nb
+
+
+@pytest.mark.parametrize("name,gen,nb", BIG_CASES)
+def test_config_tile_sizes_multicolumn_nodes(name, gen, nb):
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=32)
+    _assert_multicolumn(f, nb)
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val, variant="mkl", nthreads=8)
+    assert rc == 0
+    mask = lower_mask(f)
+    assert rel_err(got, o.arena(), mask) <= TOL_L
+    assert np.all(got[~mask] == 0.0)
+    b = A @ np.ones(f.n)
+    x = f.solve(b)
+    assert bwd_err(A, x, b) <= 1e-14
+    f.close()
+
+
 def test_kat_simple_c_through_spllt_all():
     """example/C/simple.c:25-75 call sequence via the one-shot entry point."""
     lib = api._lib.load()
@@ -281,11 +316,23 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
     this process on the same device; the exchange buffers are summed with a
     torch add (what RCCL all-reduce does across devices).  Every rank must end
     with its own subtrees + the whole top tree equal to the oracle's L."""
+    _run_partitioned(matgen.nd_like((10, 9, 8), 2), 32, 8, world, 16, "plain")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name,gen,nb", BIG_CASES)
+def test_config_tile_sizes_partitioned(name, gen, nb, world):
+    """configs 3/4/5 tile sizes through the 2- and 4-rank partition on one device"""
+    _run_partitioned(gen(), nb, 32, world, None, "mkl", check_multicolumn=nb)
+
+
+def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None):
     torch = _torch()
-    A = matgen.nd_like((10, 9, 8), 2)
     fs, bufs = [], []
     for r in range(world):
-        f, val = make_case(A, nb=32, nemin=8, prune=True, ncpu=world, panel_width=16)
+        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw)
+        if check_multicolumn:
+            _assert_multicolumn(f, check_multicolumn)
         xel = f.set_partition(r, world)
         assert xel > 0
         xb = torch.zeros(xel, dtype=torch.float64, device="cuda")
@@ -304,7 +351,7 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
     for f in fs:
         f.continue_after_exchange()
         f.wait()
-    o, rc = oracle_factor(fs[0], val)
+    o, rc = oracle_factor(fs[0], val, variant=variant, nthreads=8)
     assert rc == 0
     ref = o.arena()
     mask = lower_mask(fs[0])
@@ -336,11 +383,13 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
         ys.append(y)
         masks.append(m)
     assert int(sum(m.sum().item() for m in masks)) == n      # every entry has exactly one owner
+    torch.cuda.synchronize()
     for f, y in zip(fs, ys):
         f.solve_dev(y.data_ptr(), 3, 0, 0)
     total = torch.stack(ys).sum(dim=0)
     for y in ys:
         y.copy_(total)
+    torch.cuda.synchronize()   # torch's stream is not the engines' stream
     for f, y, m in zip(fs, ys, masks):
         f.solve_dev(y.data_ptr(), 3, 0, 1)
         f.solve_dev(y.data_ptr(), 3, 0, 2)
@@ -352,6 +401,8 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world):
     with pytest.raises(api.SplltError) as ei:      # spllt_solve needs the caller's exchange
         fs[0].solve(B[:, 0])
     assert ei.value.flag == -98
+    for f in fs:
+        f.close()
 
 
 def test_golden_vectors_gpu():
