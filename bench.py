@@ -224,15 +224,17 @@ def main():
 
         def category(l):
             if l[0] != 1:
-                return {0: "potrf", 3: "strip", 4: "chain", 5: "panelstep"}.get(int(l[0]), "other")
+                return {0: "potrf", 4: "chain"}.get(int(l[0]), "other")
+            if l[3] == 0:
+                return "marker"
             u = units[int(tiles[int(l[2])]["unit"])]
             if u["mode"] == 2:
-                return "trsm"
+                return "side"        # rows below a sub-tile: left-looking update + solve (Winv)
             if u["mode"] == 1:
                 return "between"
-            if bc_off[int(u["src_bcol0"])] == u["d_off"]:
-                return "inpanel"
-            return "next" if l[6] == 0 else "trailing"
+            # same-node updates by stream: chain = next diagonal sub-tile, side = rest of the
+            # near zone, bulk = trailing block columns
+            return {0: "next_diag", 3: "next_rest", 1: "trailing"}.get(int(l[6]), "update")
         with open(args.profile_out, "w") as fh:
             fh.write("idx kind level count tile gflop ms category\n")
             for i, (l, m) in enumerate(zip(Lh, ms)):

@@ -93,16 +93,27 @@ int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
 int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_t capacity);
 
 /* engine knobs (before the first spllt_factor on this fkeep); flags: bit 0 =
- * reserved, bit 1 = single-stream program (no lookahead),
- * bit 2 = fused strip-TRSM kernel + tile-level lookahead on latency-bound levels
- * (experiment), bit 3 = with bit 2: keep per-panel launches for the diagonal tile
- * instead of the single-workgroup tile-chain kernel, bit 4 = merge the update of
- * block column c+1 by c into the left-looking panel updates of c+1 (experiment),
- * bit 5 = fused TRSM + next-panel update launches (k_panel_step, experiment),
+ * reserved, bit 1 = single-stream program (no lookahead, program order),
  * bit 6 = issue the inter-node updates only at the end of each level (default:
- * in K slices on a third stream while the level's panel chains still run).
+ * in K slices on a separate stream while the level's panel chains still run),
+ * bit 7 = debug: the LDS of every CU is filled with signalling NaNs before every
+ * kernel launch (a kernel that reads LDS it has not written then computes NaNs),
+ * bit 8 = no CU reservation (default: the streams that carry the trailing updates
+ * are masked off 16 CUs, which the latency-critical panel-chain kernels then find
+ * free), bit 9 = the rows below the diagonal sub-tiles and the near-zone updates go
+ * to a side stream one step behind the chain instead of staying in it (fewer kernels
+ * in the chain, but every cross-stream hand-off costs 10-20 us: measured slower).
+ * Bit 10 / bit 11 = force the zone pipeline on / off (inter-node updates at the end
+ * of a level issued by destination block column so that the next level's panel chains
+ * start beside them; default: on for latency-bound problems, see schedule.hpp).
+ * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
+/* edge of the diagonal sub-tiles the single-workgroup panel-chain kernel walks
+ * (default 64 = one panel, rounded down to a multiple of the panel width; before the
+ * first spllt_factor).  Larger values let one chain kernel also solve and update the rows
+ * of its sub-tile (fewer launches, more work on one CU). */
+int spllt_hip_set_chain_block(void *fkeep, int chain_block);
 
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------
  * Call after spllt_analyse (options.prune_tree = 1, options.ncpu = nranks) and
@@ -145,10 +156,10 @@ double *spllt_hip_device_factor(void *fkeep);
 /* timings of the last factorization, milliseconds */
 int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, double *h2d_ms,
                            int *launches);
-/* program export for tests: "launches" (int64 x 10 per launch: kind, level,
- * first, count, tile, flops, stream, wait0, wait1, record), "potrf" / "chains" (PotrfUnit bytes),
- * "units" (UpdUnit bytes), "tiles" (UpdTile bytes), "strips" (StripUnit bytes), "panels"
- * (PanelStepUnit bytes), "relpos" (int32), "dinv_size" (int64); the substitution program:
+/* program export for tests: "launches" (int64 x 12 per launch: kind, level,
+ * first, count, tile, flops, stream, record, wait0..wait3), "chains" (ChainUnit bytes),
+ * "potrf" (PotrfUnit bytes), "units" (UpdUnit bytes), "tiles" (UpdTile bytes),
+ * "relpos" (int32), "dinv_size" (int64), "chain_block" (int64); the substitution program:
  * "solve_units" (SolveUnit bytes), "solve_list" (int32), "solve_tiles" (UpdTile bytes),
  * "solve_fwd" / "solve_bwd" (int64 x 4 per launch: kind, level, first, count), "solve_split"
  * (int64 x 2: launches of fwd that belong to the own branches, launches of bwd that belong

@@ -54,7 +54,7 @@ HIP_SYMBOLS = [
     "spllt_hip_get_factor", "spllt_hip_device_factor", "spllt_hip_factor_times",
     "spllt_hip_program_get", "spllt_hip_profile", "spllt_hip_last_error", "spllt_hip_version",
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
-    "spllt_hip_partition_get", "spllt_hip_solve_dev",
+    "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block",
 ]
 
 _lib = None
@@ -112,6 +112,8 @@ def load():
     lib.spllt_hip_sym_get.restype = C.c_int64
     lib.spllt_hip_set_engine.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.spllt_hip_set_engine.restype = C.c_int
+    lib.spllt_hip_set_chain_block.argtypes = [vp, C.c_int]
+    lib.spllt_hip_set_chain_block.restype = C.c_int
     lib.spllt_hip_wait.argtypes = [vp]
     lib.spllt_hip_wait.restype = C.c_int
     lib.spllt_hip_get_factor.argtypes = [vp, dp, C.c_int64]

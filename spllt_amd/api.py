@@ -27,14 +27,13 @@ UPD_UNIT_DTYPE = np.dtype([
     ("dinv_ld", "<i4"), ("lower", "<i4"), ("b_bcol0", "<i4"), ("b_seg_r0", "<i4"),
     ("atomic", "<i4"), ("a_w", "<i4"), ("a_off", "<i8")])
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
-STRIP_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("row0", "<i4"),
-                             ("nrows", "<i4"), ("pw", "<i4")])
-PANEL_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("d_off", "<i8"), ("s_off", "<i8"),
-                             ("ld", "<i4"), ("c0", "<i4"), ("pn", "<i4"), ("nrows", "<i4"),
-                             ("d_ld", "<i4"), ("d_c0", "<i4"), ("d_pn", "<i4"), ("d_rshift", "<i4"),
-                             ("s_ld", "<i4"), ("s_k", "<i4"), ("s_rshift", "<i4"), ("pad_", "<i4")])
+CHAIN_UNIT_DTYPE = np.dtype([("off", "<i8"), ("winv_off", "<i8"), ("ld", "<i4"), ("c0", "<i4"),
+                             ("pn", "<i4"), ("cs", "<i4"), ("ce", "<i4"), ("gcol", "<i4")])
+# "launches": int64 x 12 per launch
+LAUNCH_COLS = ("kind", "level", "first", "count", "tile", "flops", "stream", "record",
+               "wait0", "wait1", "wait2", "wait3")
 SOLVE_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("idx_off", "<i8"), ("w", "<i4"),
-                             ("nrow", "<i4"), ("pw", "<i4"), ("pad_", "<i4")])
+                             ("nrow", "<i4"), ("pw", "<i4"), ("cb", "<i4")])
 POTRF_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("n", "<i4"),
                              ("gcol", "<i4"), ("flags", "<i4")])
 
@@ -67,7 +66,7 @@ class Factorization:
     """One analysed pattern: owns the akeep/fkeep handle pair."""
 
     def __init__(self, n, ptr, row, nb=256, nemin=32, prune_tree=True, ncpu=1, order=None,
-                 panel_width=None, tile=None, engine_flags=0):
+                 panel_width=None, tile=None, engine_flags=0, chain_block=None):
         self.lib = _lib.load()
         self.n = int(n)
         self.ptr = np.ascontiguousarray(ptr, dtype=np.int32)
@@ -96,6 +95,8 @@ class Factorization:
             raise SplltError("spllt_analyse", self.info.flag)
         if panel_width or tile or engine_flags:
             self.lib.spllt_hip_set_engine(self.fkeep, panel_width or 0, tile or 0, engine_flags)
+        if chain_block:
+            self.lib.spllt_hip_set_chain_block(self.fkeep, int(chain_block))
         self._val_keepalive = None
 
     # ---- symbolic introspection ------------------------------------------
@@ -127,19 +128,19 @@ class Factorization:
         self.lib.spllt_hip_program_get(self.fkeep, name.encode(), raw.ctypes.data, nbytes)
         raw = raw[:nbytes]
         if name == "launches":
-            return raw.view(np.int64).reshape(-1, 10)
+            return raw.view(np.int64).reshape(-1, len(LAUNCH_COLS))
         if name == "units":
             return raw.view(UPD_UNIT_DTYPE)
         if name == "tiles":
             return raw.view(UPD_TILE_DTYPE)
-        if name in ("potrf", "chains"):
+        if name == "potrf":
             return raw.view(POTRF_UNIT_DTYPE)
+        if name == "chains":
+            return raw.view(CHAIN_UNIT_DTYPE)
+        if name == "chain_block":
+            return int(raw.view(np.int64)[0])
         if name == "relpos":
             return raw.view(np.int32)
-        if name == "strips":
-            return raw.view(STRIP_UNIT_DTYPE)
-        if name == "panels":
-            return raw.view(PANEL_UNIT_DTYPE)
         if name == "dinv_size":
             return int(raw.view(np.int64)[0])
         if name == "solve_units":

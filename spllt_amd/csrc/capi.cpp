@@ -107,7 +107,13 @@ void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, c
   Akeep* a = static_cast<Akeep*>(*akeep);
   Fkeep* f = static_cast<Fkeep*>(*fkeep);
   if (!a) { a = new (std::nothrow) Akeep(); *akeep = a; }
-  if (!f) { f = new (std::nothrow) Fkeep(); *fkeep = f; }
+  if (!f) {
+    f = new (std::nothrow) Fkeep();
+    *fkeep = f;
+    // experiment knob: default chain block of every new handle (spllt_hip_set_chain_block overrides)
+    if (f)
+      if (const char* e = std::getenv("SPLLT_CHAIN_BLOCK")) f->eo.cb = std::max(1, std::atoi(e));
+  }
   if (!a || !f) { if (info) info->flag = SPLLT_ERROR_ALLOCATION; return; }
   a->so.nb = options->nb;
   a->so.nemin = options->nemin;
@@ -499,12 +505,21 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
   if (panel_width > 0) f->eo.pw = std::min(panel_width, kPanelMax);
   if (tile > 0) f->eo.tile = tile;
-  f->eo.lookahead = (flags & 2) == 0;  // bit 1 set: single-stream program
-  f->eo.panel_step = (flags & 32) != 0;  // bit 5 set: fused TRSM + next-panel update launches (k_panel_step)
+  f->eo.lookahead = (flags & 2) == 0;       // bit 1 set: single-stream program
   f->eo.slice_between = (flags & 64) == 0;  // bit 6 set: inter-node updates only at the end of a level
-  f->eo.lazy_next = (flags & 16) != 0;  // bit 4 set: c -> c+1 update merged into the panel updates of c+1
-  f->eo.fused_strip = (flags & 4) != 0; // bit 2 set: fused strip TRSM + tile-level lookahead
-  f->eo.tile_chain = (flags & 8) == 0;  // bit 3 set: keep the per-panel launches of the diagonal tile
+  f->eo.poison_lds = (flags & 128) != 0;    // bit 7 set: debug, LDS poisoned before every launch
+  if (flags & 256) f->eo.reserve_cus = 0;   // bit 8 set: no CU reservation for the chain
+  if (flags & 1024) f->eo.zones = 1;        // bit 10 / 11: force the zone pipeline (and the atomic
+  if (flags & 2048) f->eo.zones = 0;        // trailing updates that go with it) on / off
+  f->eo.side_on_chain = (flags & 512) == 0; // bit 9 set: rows below the sub-tiles on a side stream
+  return 0;
+}
+
+int spllt_hip_set_chain_block(void* fkeep, int chain_block) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || chain_block < 1) return SPLLT_ERROR_PARAMETER;
+  if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
+  f->eo.cb = chain_block;
   return 0;
 }
 
@@ -619,12 +634,11 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     ScheduleOptions so;
     so.pw = f->eo.pw;
     so.tile = f->eo.tile;
+    so.cb = f->eo.cb;
     so.lookahead = f->eo.lookahead;
-    so.lazy_next = f->eo.lazy_next;
     so.slice_between = f->eo.slice_between;
-    so.panel_step = f->eo.panel_step;
-    so.fused_strip = f->eo.fused_strip;
-    so.tile_chain = f->eo.tile_chain;
+    so.side_on_chain = f->eo.side_on_chain;
+    so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
     std::vector<int> owner;
     if (f->eo.nranks > 1) {
       assign_owners(*f->S, f->eo.nranks, owner);
@@ -645,7 +659,8 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     for (const Launch& l : P->launches) {
       v.push_back(l.kind); v.push_back(l.level); v.push_back(l.first);
       v.push_back(l.count); v.push_back(l.tile); v.push_back((int64_t)l.flops);
-      v.push_back(l.stream); v.push_back(l.wait0); v.push_back(l.wait1); v.push_back(l.record);
+      v.push_back(l.stream); v.push_back(l.record);
+      for (int w : l.wait) v.push_back(w);
     }
     return raw(v.data(), v.size() * sizeof(int64_t));
   }
@@ -653,16 +668,15 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "units") return raw(P->units.data(), P->units.size() * sizeof(UpdUnit));
   if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
-  if (k == "strips") return raw(P->strip_units.data(), P->strip_units.size() * sizeof(StripUnit));
-  if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelStepUnit));
-  if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(PotrfUnit));
+  if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
+  if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }
   if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
   if (k.rfind("solve_", 0) == 0) {
     // the substitution program (partition-aware like the factor program)
     SolveProgram sp;
     std::vector<int> owner;
     if (f->eo.nranks > 1) assign_owners(*f->S, f->eo.nranks, owner);
-    build_solve_program(*f->S, f->eo.pw > 0 ? f->eo.pw : kPanelMax, sp,
+    build_solve_program(*f->S, f->eo.pw > 0 ? f->eo.pw : kPanelMax, P->cb, sp,
                         f->eo.nranks > 1 ? owner.data() : nullptr, f->eo.rank);
     if (k == "solve_units") return raw(sp.units.data(), sp.units.size() * sizeof(SolveUnit));
     if (k == "solve_list") return raw(sp.diag_list.data(), sp.diag_list.size() * sizeof(int));

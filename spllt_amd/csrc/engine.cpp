@@ -56,12 +56,16 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   ScheduleOptions so;
   so.pw = opt_.pw;
   so.tile = opt_.tile;
+  so.cb = opt_.cb;
   so.lookahead = opt_.lookahead;
-  so.lazy_next = opt_.lazy_next;
   so.slice_between = opt_.slice_between;
-  so.panel_step = opt_.panel_step;
-  so.fused_strip = opt_.fused_strip;
-  so.tile_chain = opt_.tile_chain;
+  so.side_on_chain = opt_.side_on_chain;
+  {
+    const bool lb = latency_bound(*S_, std::min(opt_.pw, kPanelMax));
+    if (opt_.reserve_cus < 0) opt_.reserve_cus = lb ? 32 : 0;
+    if (opt_.zones < 0) opt_.zones = lb ? 1 : 0;
+    so.zones = opt_.zones != 0;
+  }
   if (opt_.nranks > 1) {
     assign_owners(*S_, opt_.nranks, owner_);
     so.node_owner = owner_.data();
@@ -81,31 +85,48 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
 
 int Engine::upload() {
   const Symbolic& S = *S_;
-  // the panel chain is latency-critical: give its stream the highest priority
+  // The chain and side streams carry the latency-critical kernels: highest priority, all
+  // CUs.  The bulk and far streams carry the updates that run BESIDE a chain: lowest
+  // priority and masked off the last `reserve_cus` CUs, so that a chain kernel (one
+  // workgroup, up to 145 KB of LDS) and the side launches always find a free CU instead of
+  // waiting for a bulk workgroup to retire (measured, scripts/cumask_probe.hip: 14 us
+  // launch-to-completion beside a masked bulk kernel, 30 us beside an unmasked one; masking
+  // the FIRST bits instead gives erratic 13-450 us).  The wide stream (launches that have
+  // the chip to themselves) is not masked.
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");
-  HIPCHK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio_hi), "hipStreamCreate");
-  // Optional CU reservation (experiment knob SPLLT_HIP_RESERVE_CUS=n): the bulk
-  // stream is masked off n CUs so that the latency-critical panel kernels
-  // always find a free CU instead of queueing behind bulk workgroups.
   if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);
-  int reserve = 0;
+  int reserve = opt_.reserve_cus;
   if (const char* e = std::getenv("SPLLT_HIP_RESERVE_CUS")) reserve = std::atoi(e);
-  if (reserve > 0) {
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device_), "device props");
-    const int ncu = prop.multiProcessorCount;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_), "device props");
+  const int ncu = prop.multiProcessorCount;
+  if (reserve < 0 || reserve * 2 > ncu || !opt_.lookahead) reserve = 0;
+  // At most four hardware queues carry the five streams of the program: the runtime
+  // multiplexes streams onto a handful of hardware queues, and streams that share one
+  // serialise (five queues of our own: no overlap at all, 33.0 ms = the serialized 33.2 ms).
+  // The wide stream only runs when the chains of a level are done -> chain queue; the side
+  // stream exists only in the side-stream variant of the program.
+  auto masked_stream = [&](hipStream_t* st) -> hipError_t {
+    if (reserve <= 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo);
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    // reserve CUs spread over the XCDs (CU ids are dealt round-robin to XCDs)
-    for (int cu = 0; cu < ncu; ++cu)
-      if (cu >= reserve) mask[cu / 32] |= 1u << (cu % 32);
-    HIPCHK(hipExtStreamCreateWithCUMask(&bulk_, (uint32_t)mask.size(), mask.data()), "cu-mask stream");
-  } else {
-    HIPCHK(hipStreamCreateWithPriority(&bulk_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
-  }
-  HIPCHK(hipStreamCreateWithPriority(&far_, hipStreamNonBlocking, prio_lo), "hipStreamCreate");
+    for (int cu = 0; cu < ncu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+  };
+  HIPCHK(hipStreamCreateWithPriority(&streams_[ST_CHAIN], hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+  streams_[ST_WIDE] = streams_[ST_CHAIN];
+  if (opt_.side_on_chain || !opt_.lookahead)
+    streams_[ST_SIDE] = streams_[ST_CHAIN];
+  else
+    HIPCHK(hipStreamCreateWithPriority(&streams_[ST_SIDE], hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+  HIPCHK(masked_stream(&streams_[ST_BULK]), "bulk stream");
+  if (std::getenv("SPLLT_FAR_ON_BULK"))   // experiment: three queues
+    streams_[ST_FAR] = streams_[ST_BULK];
+  else
+    HIPCHK(masked_stream(&streams_[ST_FAR]), "far stream");
+  stream_ = streams_[ST_CHAIN];
   dag_events_.resize(prog_.nevents);
   for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
@@ -144,10 +165,7 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_bc_w_, w), "upload bc_w");
   HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
   HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
-  HIPCHK(dev_upload(&d_potrf_, prog_.potrf_units), "upload potrf units");
-  HIPCHK(dev_upload(&d_strips_, prog_.strip_units), "upload strip units");
   HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
-  HIPCHK(dev_upload(&d_panels_, prog_.panel_units), "upload panel-step units");
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
@@ -156,44 +174,41 @@ int Engine::upload() {
 }
 
 Engine::~Engine() {
-  if (stream_) hipStreamSynchronize(stream_);
-  if (bulk_) hipStreamSynchronize(bulk_);
+  for (hipStream_t st : streams_)
+    if (st) hipStreamSynchronize(st);
   for (auto& e : dag_events_) if (e) hipEventDestroy(e);
-  if (bulk_) hipStreamDestroy(bulk_);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_potrf_); hipFree(d_strips_); hipFree(d_chain_); hipFree(d_panels_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   if (ev_h2d_) hipEventDestroy(ev_h2d_);
-  if (far_) hipStreamDestroy(far_);
-  if (stream_) hipStreamDestroy(stream_);
+  for (int i = 0; i < ST_COUNT; ++i) {
+    bool alias = false;
+    for (int j = 0; j < i; ++j) alias = alias || streams_[j] == streams_[i];
+    if (streams_[i] && !alias) hipStreamDestroy(streams_[i]);
+  }
 }
 
 int Engine::enqueue_launch(const Launch& l, bool serial) {
-  hipStream_t st = (serial || l.stream == 0) ? stream_ : (l.stream == 2 ? far_ : bulk_);
-  if (!serial) {
-    if (l.wait0 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait0], 0), "stream wait");
-    if (l.wait1 >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[l.wait1], 0), "stream wait");
-  }
+  hipStream_t st = serial ? stream_ : streams_[l.stream];
+  if (!serial)
+    for (int w : l.wait)
+      if (w >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[w], 0), "stream wait");
   if (l.count > 0 && l.kind != L_EXCHANGE) {
-    if (l.kind == L_POTRF)
-      launch_potrf(st, d_potrf_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
-    else if (l.kind == L_STRIP)
-      launch_strip(st, l.tile, d_tiles_ + l.first, l.count, d_strips_, d_L_, d_dinv_);
-    else if (l.kind == L_PANEL)
-      launch_panel_step(st, d_tiles_ + l.first, l.count, d_panels_, d_L_, d_dinv_);
-    else if (l.kind == L_CHAIN)
-      launch_tile_chain(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
-    else {
-      // two-stream program: panel-chain launches run at raised wave priority and
-      // the trailing updates leave part of every CU free for them
-      const bool two = !serial && opt_.lookahead;
-      const int prio = (two && l.stream == 0) ? chain_prio_ : 0;
+    if (opt_.poison_lds) launch_poison_lds(st);
+    if (l.kind == L_CHAIN) {
+      launch_chain_panel(st, d_chain_ + l.first, l.count, l.tile, d_L_, d_dinv_, d_flag_);
+    } else if (l.kind == L_WINV) {
+      launch_winv(st, d_chain_ + l.first, l.count, d_L_, d_dinv_);
+    } else {
+      // multi-stream program: chain / side launches run at raised wave priority
+      const bool multi = !serial && opt_.lookahead;
+      const int prio = (multi && (l.stream == ST_CHAIN || l.stream == ST_SIDE)) ? chain_prio_ : 0;
       int pad = 0;
-      if (two && l.stream >= 1 && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
+      if (multi && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
       launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
                     d_relpos_, d_rlist_, d_dinv_, prio, pad);
     }
@@ -236,7 +251,8 @@ int Engine::enqueue_program() {
   int rc = enqueue_range(0, (size_t)xchg_idx_);
   if (rc) return rc;
   const Launch& X = prog_.launches[xchg_idx_];
-  if (X.wait0 >= 0) HIPCHK(hipStreamWaitEvent(stream_, dag_events_[X.wait0], 0), "exchange wait");
+  for (int w : X.wait)
+    if (w >= 0) HIPCHK(hipStreamWaitEvent(stream_, dag_events_[w], 0), "exchange wait");
   int64_t xo = 0;
   for (int b : top_bcols_) {
     const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
@@ -251,8 +267,7 @@ int Engine::enqueue_program() {
 
 int Engine::sync_phase() {
   if (status_) return status_;
-  HIPCHK(hipStreamSynchronize(stream_), "stream sync");
-  HIPCHK(hipStreamSynchronize(bulk_), "stream sync");
+  for (hipStream_t st : streams_) HIPCHK(hipStreamSynchronize(st), "stream sync");
   return 0;
 }
 
@@ -340,7 +355,7 @@ int Engine::download(double* out, int64_t count) {
 int Engine::prepare_solve() {
   if (solve_ready_) return 0;
   const Symbolic& S = *S_;
-  build_solve_program(S, prog_.pw, sprog_, opt_.nranks > 1 ? owner_.data() : nullptr, opt_.rank);
+  build_solve_program(S, prog_.pw, prog_.cb, sprog_, opt_.nranks > 1 ? owner_.data() : nullptr, opt_.rank);
   HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
   HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
   HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");

@@ -18,12 +18,14 @@ namespace spx {
 struct EngineOptions {
   int pw = 64;
   int tile = 128;
-  bool lookahead = true;   // two-stream program (panel chain overlaps trailing updates)
-  bool panel_step = false; // fused TRSM + next-panel update launches on latency-bound levels
+  int cb = 64;             // chain block (edge of the diagonal sub-tiles of the panel chain)
+  bool lookahead = true;   // multi-stream program (panel chain overlaps trailing updates)
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
-  bool lazy_next = false;  // merge the c -> c+1 update into the panel updates of c+1
-  bool fused_strip = false; // one k_trsm_strip launch per block column for the sub-diagonal rows
-  bool tile_chain = true;   // (with fused_strip) single-workgroup panel chain per diagonal tile
+  bool side_on_chain = true;   // see ScheduleOptions
+  bool poison_lds = false; // debug: poison the LDS of every CU before every launch
+  int reserve_cus = -1;    // CUs the bulk / far streams are masked off (0: no mask; -1: 32 when the
+                           // problem is latency-bound (schedule.hpp), else 0)
+  int zones = -1;          // zone pipeline of the inter-node updates (1 / 0; -1: when latency-bound)
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
 };
 
@@ -94,14 +96,15 @@ class Engine {
   int status_ = 0;
   std::string err_;
   int device_ = 0;
-  hipStream_t stream_ = nullptr;       // panel stream (stream 0 of the program)
-  hipStream_t bulk_ = nullptr;         // bulk stream (stream 1)
-  hipStream_t far_ = nullptr;          // far stream (stream 2): early inter-node update slices
-  int chain_prio_ = 1;                 // s_setprio for panel-stream update launches
-  // dynamic-LDS padding (bytes) of the trailing updates that run beside a panel chain:
-  // 64-tile launches (< 4096 large tiles, i.e. the chain is the bottleneck) are capped at
-  // 2 workgroups per CU so that chain kernels find free slots; large launches are not capped
-  int bulk_pad128_ = 0, bulk_pad64_ = 49152;
+  // streams of the program (schedule.hpp StreamId).  stream_ = chain stream, also the
+  // stream every caller-visible operation (H2D, pack, solve) is ordered on.
+  hipStream_t stream_ = nullptr;
+  hipStream_t streams_[ST_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int chain_prio_ = 1;                 // s_setprio for chain / side update launches
+  // optional dynamic-LDS padding (bytes) of the trailing updates that run beside a panel
+  // chain (caps their workgroups per CU); off by default: the bulk streams are masked off
+  // reserve_cus CUs instead
+  int bulk_pad128_ = 0, bulk_pad64_ = 0;
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
   bool pending_ = false;
@@ -125,10 +128,7 @@ class Engine {
   int* d_bc_w_ = nullptr;
   UpdUnit* d_units_ = nullptr;
   UpdTile* d_tiles_ = nullptr;
-  PotrfUnit* d_potrf_ = nullptr;
-  StripUnit* d_strips_ = nullptr;
-  PotrfUnit* d_chain_ = nullptr;
-  PanelStepUnit* d_panels_ = nullptr;
+  ChainUnit* d_chain_ = nullptr;
   // device solve (built on first use)
   SolveProgram sprog_;
   bool solve_ready_ = false;

@@ -11,9 +11,12 @@
 //   k_scatter_block a26 spllt_scatter_block (:1122-1160) extend-add
 //   k_solve_diag / k_solve_strip   forward / backward substitution on the device-resident
 //                   factor (reference src/spllt_solve_mod.F90), up to 4 right-hand sides
-//   experimental variants of the panel chain (not in the default program, kept with
-//   their tests because the measurements in DESIGN.md refer to them):
-//   k_trsm_strip (flag 4), k_tile_chain (flag 4), k_panel_step (flag 32)
+//   k_chain_panel   one step of the panel chain of a diagonal sub-tile in ONE workgroup:
+//                   POTRF of the panel's diagonal block, the rows of the sub-tile below it,
+//                   their update of the rest of the sub-tile, and the matrix Winv that turns
+//                   the left-looking update + TRSM of every row below the sub-tile into one
+//                   k_update (TRSM mode) product
+//   k_poison_lds    debug: fills the LDS of every CU with signalling-NaN patterns
 //
 // Storage convention: every block column of L is a
 // row-major (rows x width) matrix; all products are C = A * B^T with both
@@ -111,16 +114,16 @@ __device__ unsigned long long g_potrf_stamps[32];
 #endif
 
 struct PotrfShared {
-  double T[64 * TLD];
   double X[64 * TLD];
   double DI[4][16 * DLD];
   double RI[64];  // reciprocals of the diagonal of L
+  double T[64 * TLD];  // last: k_chain_panel reuses it (and the dynamic LDS behind it) as its U buffer
 };
 
 // Factor (and invert) one <=64 x <=64 block held at A (row stride ld); the whole
-// workgroup takes part.  D receives inv(L) (row-major, ld = n).
+// workgroup takes part.  D receives inv(L) (row-major, row stride ldd).
 __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict__ A, int ld, int n,
-                                             double* __restrict__ D, int gcol, int flags,
+                                             double* __restrict__ D, int ldd, int gcol, int flags,
                                              int* __restrict__ flag) {
   double (&T)[64 * TLD] = sh.T;
   double (&X)[64 * TLD] = sh.X;
@@ -134,21 +137,28 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
   const bool do_chol = !(u.flags & 1);
   STAMP(0);
   // identity-padded lower triangle: thread t owns 16 consecutive columns of row t/4
+  // (callers may run more than 256 threads: only the first 256 load / store / compute here,
+  // the others just take part in the barriers)
   const int li = tid >> 2, lj0 = (tid & 3) * 16;
-  {
+  if (li < 64) {
+    // unconditional loads at clamped addresses (all 16 in flight at once; a load under a
+    // condition is compiled into a branch with its own wait), selection afterwards
     double v[16];
+    const double* arow = A + (int64_t)(li < n ? li : n - 1) * ld;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = arow[lj0 + e < n ? lj0 + e : n - 1];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = lj0 + e;
-      v[e] = (li < n && j <= li) ? A[(int64_t)li * ld + j] : ((li == j) ? 1.0 : 0.0);
+      v[e] = (li < n && j <= li) ? v[e] : ((li == j) ? 1.0 : 0.0);
     }
-    if (li < np) {
+    // all 64 rows are written: the matrix-core steps of the callers read whole
+    // 16-row fragments of X, and stale LDS may hold NaN bit patterns
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        T[li * TLD + lj0 + e] = v[e];
-        X[li * TLD + lj0 + e] = 0.0;
-        if (!do_chol && lj0 + e == li) RI[li] = 1.0 / v[e];
-      }
+    for (int e = 0; e < 16; ++e) {
+      T[li * TLD + lj0 + e] = v[e];
+      X[li * TLD + lj0 + e] = 0.0;
+      if (!do_chol && lj0 + e == li) RI[li] = 1.0 / v[e];
     }
   }
   __syncthreads();
@@ -159,10 +169,15 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
       const int I = J + w;
       if (I < nblk) {
         d4 acc = ld_c(T, I * 16, J * 16, lane);
-        for (int k = 0; k < J * 16; k += 4) {
-          const double a = -T[(I * 16 + lr) * TLD + k + lq];
-          const double b = T[(J * 16 + lr) * TLD + k + lq];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int K = 0; K < J; ++K) {
+          double a[4], b[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a[t] = -T[(I * 16 + lr) * TLD + K * 16 + 4 * t + lq];
+            b[t] = T[(J * 16 + lr) * TLD + K * 16 + 4 * t + lq];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
         }
         st_c(T, I * 16, J * 16, lane, acc);
       }
@@ -296,11 +311,12 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
       const int j = lj0 + e;
       if (j < n) {
         if (do_chol && j <= li) A[(int64_t)li * ld + j] = T[li * TLD + j];
-        D[li * n + j] = X[li * TLD + j];
+        D[(int64_t)li * ldd + j] = X[li * TLD + j];
       }
     }
   }
   STAMP(16);
+  (void)np;
 }
 
 __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
@@ -310,258 +326,174 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
   __shared__ PotrfShared sh;
   __builtin_amdgcn_s_setprio(3);
   const PotrfUnit u = units[blockIdx.x];
-  potrf64_body(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.gcol, u.flags, flag);
+  potrf64_body(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.n, u.gcol, u.flags, flag);
 }
 
 // ---------------------------------------------------------------------------
-// The whole panel chain of one diagonal tile (w <= 256) in ONE workgroup:
-//   for every 64-wide panel p:  update the panel's block column inside the tile
-//   by the previous panels, factor + invert its diagonal block, solve the
-//   tile rows below it.
-// It replaces 3*np-1 dependent launches on the critical path (each of which has
-// to win CU slots against the concurrently running trailing update) by a single
-// resident workgroup.  The tile-local products read their MFMA operands
-// straight from global memory (the tile is 512 KB and L2-resident).
+// One step of the panel chain (ChainUnit), ONE workgroup per block column: panel
+// [c0, c0+pn) of the diagonal sub-tile [cs, ce) x [cs, ce) of a block column
+// (a11 spllt_factor_diag_block restricted to the sub-tile, right-looking):
+//   1. L_pp = chol(A_pp), inv(L_pp) -> last pn columns of Winv           (potrf64_body)
+//   2. X = A[c0+pn:ce, c0:c0+pn] inv(L_pp)^T                          (rows of the sub-tile)
+//   3. A[c0+pn:ce, c0+pn:ce] -= X X^T  (lower part)
+// k_winv (side stream, off the chain) completes
+//      Winv = [ -inv(L_pp) A[c0:c0+pn, cs:c0] | inv(L_pp) ]           in the dinv scratch,
+// which turns the left-looking update AND the triangular solve of every row below
+// the sub-tile into ONE product with K = c0+pn-cs (k_update, TRSM mode):
+//   X_r = [X_r,cs:c0 | A_r,c0:c0+pn] Winv^T
+// so the rows below never enter the chain: per panel the critical path is this one
+// kernel instead of a POTRF, a TRSM and an update launch.
+// LDS: PotrfShared, whose T (dead after step 1) and the dynamic LDS behind it hold
+// U = X (up to ce-c0-pn rows, zero padded to a multiple of 16).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_chain(const PotrfUnit* __restrict__ units,
-                                                    double* __restrict__ L,
-                                                    double* __restrict__ dinv,
-                                                    int* __restrict__ flag) {
-  __shared__ PotrfShared sh;
-  const PotrfUnit u = units[blockIdx.x];   // off = block column, n = tile order, flags = panel width
-  const int w = u.ld, nt = u.n, pw = u.flags;
+constexpr int kChainThreads = 768;    // 12 waves: a single wave issues an fp64 MFMA only every
+                                      // ~150 cycles; three per SIMD fit the register budget of the POTRF part (158 VGPRs)
+
+__global__ __launch_bounds__(kChainThreads) void k_chain_panel(const ChainUnit* __restrict__ units,
+                                                               double* __restrict__ L,
+                                                               double* __restrict__ dinv,
+                                                               int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double chain_smem[];
+  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(chain_smem);
+  double* U = sh.T;
+  __builtin_amdgcn_s_setprio(3);
+  const ChainUnit u = units[blockIdx.x];
+  constexpr int NW = kChainThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int ld = u.ld, c0 = u.c0, pn = u.pn, cq = u.c0 - u.cs;
+  const int ldw = cq + pn;
   double* A = L + u.off;
-  int64_t slot = u.dinv_off;
-  for (int c0 = 0; c0 < nt; c0 += pw) {
-    const int pn = min(pw, nt - c0);
-    const int nct = (pn + 15) >> 4;
-    if (c0 > 0) {
-      // (a) A[r][c0+j] -= sum_{k<c0} A[r][k] A[c0+j][k],  r in [c0, nt), lower part
-      const int nrt = (nt - c0 + 15) >> 4;
-      for (int t = wave; t < nrt * nct; t += 4) {
-        const int rt = t / nct, ct = t - rt * nct;
-        if (rt < ct) continue;  // entirely above the diagonal
-        const int rbase = c0 + rt * 16, cbase = c0 + ct * 16;
-        d4 acc;
+  double* W = dinv + u.winv_off;
+  potrf64_body(sh, A + (int64_t)c0 * ld + c0, ld, pn, W + cq, ldw, u.gcol, 0, flag);
+  __syncthreads();   // T has been read back: it may be overwritten now
+  STAMP(17);
+  // From here on every inner loop runs its full 16 k-steps / 4 column blocks without
+  // branches and loads at clamped addresses without conditions (a load under a condition
+  // is compiled into a branch with its own wait; unconditional ones are requested
+  // together): X is zero outside [0, pn) x [0, pn) except for the identity padding of its
+  // diagonal, which only ever meets zeroed or discarded operands.
+  // ---- 2. rows of the sub-tile below the panel: X = A inv(L_pp)^T ----------------
+  // one (16-row strip, 16-column block) pair per wave and turn
+  const int r1 = c0 + pn;
+  const int nrem = u.ce - r1;
+  const int ns = (nrem + 15) >> 4;
+  for (int t = wave; t < ns * 4; t += NW) {
+    const int s = t >> 2, jb = t & 3;
+    // operands at clamped addresses, no selection: rows beyond the sub-tile duplicate its
+    // last row (their results are never used), columns k >= pn meet the zeros of X, and the
+    // padding columns of the result are cleared at the store
+    const int row = r1 + s * 16 + lr;
+    const double* ap = A + (int64_t)(row < u.ce ? row : u.ce - 1) * ld + c0;
+    double av[16], xv[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + lq + 4 * r, col = cbase + lr;
-          acc[r] = (row < nt && col < c0 + pn) ? A[(int64_t)row * w + col] : 0.0;
-        }
-        const int ra = min(rbase + lr, nt - 1), rb = min(cbase + lr, nt - 1);
-        const double* pa = A + (int64_t)ra * w + lq;
-        const double* pb = A + (int64_t)rb * w + lq;
-        // c0 is a multiple of the panel width (64): 16 k-steps per chunk, all 32
-        // operand loads of a chunk in flight before its MFMAs
-        for (int k0 = 0; k0 < c0; k0 += 64) {
-          double av[16], bv[16];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int k = k0 + 4 * t;
-            av[t] = k < c0 ? pa[k] : 0.0;
-            bv[t] = k < c0 ? pb[k] : 0.0;
-          }
-#pragma unroll
-          for (int t = 0; t < 16; ++t)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[t], bv[t], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rbase + lq + 4 * r, col = cbase + lr;
-          if (row < nt && col < c0 + pn && row >= col) A[(int64_t)row * w + col] = acc[r];
-        }
-      }
-      __syncthreads();
+    for (int kt = 0; kt < 16; ++kt) {
+      const int k = 4 * kt + lq;
+      av[kt] = ap[k < pn ? k : pn - 1];
+      xv[kt] = sh.X[(jb * 16 + lr) * TLD + k];
     }
-    // (b) factor + invert the diagonal block of the panel
-    potrf64_body(sh, A + (int64_t)c0 * w + c0, w, pn, dinv + slot, u.gcol + c0, 0, flag);
-    __syncthreads();
-    // (c) rows below the panel inside the tile: X = A * inv(L_pp)^T, one 16-row
-    // tile per wave (its K operand is loaded completely before it is overwritten)
-    {
-      const double* D = dinv + slot;
-      const int r1 = c0 + pn;
-      const int nrt = (nt - r1 + 15) >> 4;
-      const int ksteps = (pn + 3) >> 2;
-      for (int rt = wave; rt < nrt; rt += 4) {
-        const int rbase = r1 + rt * 16;
-        const int ra = min(rbase + lr, nt - 1);
-        double av[16];
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int k = 4 * t + lq;
-          const double v = A[(int64_t)ra * w + c0 + min(k, pn - 1)];
-          av[t] = (t < ksteps && k < pn && rbase + lr < nt) ? v : 0.0;
-        }
-        for (int ct = 0; ct < nct; ++ct) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
-          const int jrow = min(ct * 16 + lr, pn - 1);
-          double bv[16];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int k = min(4 * t + lq, pn - 1);
-            bv[t] = D[jrow * pn + k];
-          }
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int k = 4 * t + lq;
-            const double b = (t < ksteps && k < pn && ct * 16 + lr < pn) ? bv[t] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], b, acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = rbase + lq + 4 * r, col = ct * 16 + lr;
-            if (row < nt && col < pn) A[(int64_t)row * w + c0 + col] = acc[r];
-          }
-        }
-      }
+    for (int kt = 0; kt < 16; kt += 2) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], xv[kt], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], xv[kt + 1], acc1, 0, 0, 0);
     }
-    __syncthreads();
-    slot += (int64_t)pn * pn;
+    // the four waves of a strip read the same rows of A before any of them stores:
+    // each stores only its own 16 columns, and those are read by ... every wave of
+    // the strip.  So the stores wait for the strip's loads: barrier below.
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      U[(s * 16 + lq + 4 * r) * TLD + jb * 16 + lr] = (jb * 16 + lr < pn) ? acc0[r] + acc1[r] : 0.0;
   }
+  __syncthreads();
+  // X back to the arena (the in-place overwrite is safe now: every load of step 3 is done)
+  for (int e = tid; e < nrem * 64; e += kChainThreads) {
+    const int rr = e >> 6, col = e & 63;
+    if (col < pn) A[(int64_t)(r1 + rr) * ld + c0 + col] = U[rr * TLD + col];
+  }
+  STAMP(19);
+  // ---- 3. A[r1:ce, r1:ce] -= X X^T (lower), 16x16 tiles dealt to the waves ---------
+  {
+    const int npairs = ns * (ns + 1) / 2;
+    int ib = 0, base = 0;   // pairs of row strip ib occupy [base, base + ib]
+    for (int p = wave; p < npairs; p += NW) {
+      while (p > base + ib) { base += ib + 1; ++ib; }
+      const int jb = p - base;
+      d4 acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
+      bool ok[4];
+      const int col = r1 + jb * 16 + lr;
+      const int colc = col < u.ce ? col : u.ce - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r1 + ib * 16 + lq + 4 * r;
+        ok[r] = row < u.ce && col < u.ce && row >= col;
+        acc0[r] = A[(int64_t)(row < u.ce ? row : u.ce - 1) * ld + colc];   // unconditional, clamped
+      }
+      double av[16], bv[16];
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+        av[kt] = -U[(ib * 16 + lr) * TLD + 4 * kt + lq];
+        bv[kt] = U[(jb * 16 + lr) * TLD + 4 * kt + lq];
+      }
+#pragma unroll
+      for (int kt = 0; kt < 16; kt += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], bv[kt], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], bv[kt + 1], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r1 + ib * 16 + lq + 4 * r;
+        if (ok[r]) A[(int64_t)row * ld + col] = acc0[r] + acc1[r];
+      }
+    }
+  }
+  STAMP(20);
 }
 
-// ---------------------------------------------------------------------------
-// One panel step below its POTRF (PanelStepUnit).  Workgroup = 32 rows:
-//   Xi = A_i * inv(L_pp)^T                     (the TRSM of its rows, stored)
-//   Xd = A_d * inv(L_pp)^T                     (rows of the next panel's diagonal
-//                                               block, recomputed by every workgroup)
-//   D[i, next panel] -= [S_i | O_i | Xi] * [S_d | O_d | Xd]^T
-// with S = previous block column, O = source block column's panels before p
-// (MFMA operands straight from global/L2) and the panel itself from LDS.  It
-// replaces the TRSM launch, the left-looking update launch of the next panel
-// and the separate block-column c -> c+1 update on the critical path.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_panel_step(const UpdTile* __restrict__ tiles,
-                                                    const PanelStepUnit* __restrict__ units,
-                                                    double* __restrict__ L,
-                                                    const double* __restrict__ dinv) {
-  __shared__ double Ai[32 * TLD];
-  __shared__ double Ad[64 * TLD];
-  __builtin_amdgcn_s_setprio(2);
-  const UpdTile tl = tiles[blockIdx.x];
-  const PanelStepUnit u = units[tl.unit];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int pn = u.pn, ld = u.ld;
-  const int rb = u.c0 + pn;          // first stored row below the diagonal block
-  const int i0 = tl.ti * 32;         // first row of this tile inside the region
-  const bool has_dest = u.d_off >= 0;
+// W part of Winv for the panels of a launch of k_chain_panel (same ChainUnit): one workgroup
+// per unit, 16 x 16 tiles dealt to its waves.  Side stream: only the rows below the sub-tile
+// wait for it.
+__global__ __launch_bounds__(kChainThreads) void k_winv(const ChainUnit* __restrict__ units,
+                                                        const double* __restrict__ L,
+                                                        double* __restrict__ dinv) {
+  __shared__ double X[64 * TLD];
+  const ChainUnit u = units[blockIdx.x];
+  constexpr int NW = kChainThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int ld = u.ld, c0 = u.c0, pn = u.pn, cq = u.c0 - u.cs;
+  const int ldw = cq + pn;
   const double* A = L + u.off;
-  // ---- stage A_i (32 x pn) and A_d (d_pn x pn), zero padded ----------------
-  {
-    const int r = tid >> 3, k0 = (tid & 7) * 8;
-    const bool ok = i0 + r < u.nrows;
-    const double* src = A + (int64_t)(rb + (ok ? i0 + r : 0)) * ld + u.c0;
-    double v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[min(k0 + e, pn - 1)];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Ai[r * TLD + k0 + e] = (ok && k0 + e < pn) ? v[e] : 0.0;
-  }
-  if (has_dest) {
-    const int r = tid >> 2, k0 = (tid & 3) * 16;
-    const bool ok = r < u.d_pn;
-    const double* src = A + (int64_t)(rb + (ok ? r : 0)) * ld + u.c0;
-    double v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = src[min(k0 + e, pn - 1)];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Ad[r * TLD + k0 + e] = (ok && k0 + e < pn) ? v[e] : 0.0;
+  double* W = dinv + u.winv_off;
+  // inv(L_pp), zero padded to 64 x 64
+  for (int e = tid; e < 64 * 64; e += kChainThreads) {
+    const int i = e >> 6, k = e & 63;
+    const double v = W[(int64_t)(i < pn ? i : pn - 1) * ldw + cq + (k < pn ? k : pn - 1)];
+    X[i * TLD + k] = (i < pn && k < pn) ? v : 0.0;
   }
   __syncthreads();
-  // ---- Xi, Xd = A * Dinv^T ---------------------------------------------------
-  const double* D = dinv + u.dinv_off;
-  const int rf = w & 1, cfb = (w >> 1) * 2;   // Xi / update fragments of this wave: (rf, cfb), (rf, cfb+1)
-  d4 xd[4], xi[2];
+  const int nib = (pn + 15) >> 4, njb = (cq + 15) >> 4;
+  for (int t = wave; t < nib * njb; t += NW) {
+    const int ib = t % nib, jb = t / nib;
+    const bool jok = jb * 16 + lr < cq;
+    const double* bp = A + u.cs + (jok ? jb * 16 + lr : cq - 1);
+    double bv[16], av[16];
 #pragma unroll
-  for (int cf = 0; cf < 4; ++cf) {
-    double bv[16];
-    const int jrow = min(cf * 16 + lr, pn - 1);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) bv[t] = D[jrow * pn + min(4 * t + lq, pn - 1)];
-    const bool jok = cf * 16 + lr < pn;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    d4 acci = {0.0, 0.0, 0.0, 0.0};
-    const bool mine = (cf >> 1) == (w >> 1);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const double b = (jok && 4 * t + lq < pn) ? bv[t] : 0.0;
-      if (has_dest) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[(w * 16 + lr) * TLD + 4 * t + lq], b, acc, 0, 0, 0);
-      if (mine) acci = __builtin_amdgcn_mfma_f64_16x16x4f64(Ai[(rf * 16 + lr) * TLD + 4 * t + lq], b, acci, 0, 0, 0);
+    for (int kt = 0; kt < 16; ++kt) {
+      const int k = 4 * kt + lq;
+      bv[kt] = bp[(int64_t)(c0 + (k < pn ? k : pn - 1)) * ld];
+      av[kt] = X[(ib * 16 + lr) * TLD + k];
     }
-    xd[cf] = acc;
-    if (mine) xi[cf & 1] = acci;
-  }
-  __syncthreads();
-  // ---- write back: Xd -> Ad, Xi -> Ai and L (final values of the panel rows) --
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int cf = 0; cf < 4; ++cf)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Ad[(w * 16 + lq + 4 * r) * TLD + cf * 16 + lr] = xd[cf][r];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
+    for (int kt = 0; kt < 16; kt += 2) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], bv[kt], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], bv[kt + 1], acc1, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = rf * 16 + lq + 4 * r, col = (cfb + c) * 16 + lr;
-      Ai[row * TLD + col] = xi[c][r];
-      if (i0 + row < u.nrows && col < pn)
-        L[u.off + (int64_t)(rb + i0 + row) * ld + u.c0 + col] = xi[c][r];
-    }
-  if (!has_dest) return;
-  __syncthreads();
-  // ---- update of the next panel ------------------------------------------------
-  d4 acc[2];
-  acc[0] = (d4){0.0, 0.0, 0.0, 0.0};
-  acc[1] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const double a = Ai[(rf * 16 + lr) * TLD + 4 * t + lq];
-    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ad[((cfb + 0) * 16 + lr) * TLD + 4 * t + lq], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ad[((cfb + 1) * 16 + lr) * TLD + 4 * t + lq], acc[1], 0, 0, 0);
-  }
-  const bool aok = i0 + rf * 16 + lr < u.nrows;
-  const int arow = rb + (aok ? i0 + rf * 16 + lr : 0);
-  const bool b0ok = (cfb + 0) * 16 + lr < u.d_pn, b1ok = (cfb + 1) * 16 + lr < u.d_pn;
-  const int b0row = rb + (b0ok ? (cfb + 0) * 16 + lr : 0);
-  const int b1row = rb + (b1ok ? (cfb + 1) * 16 + lr : 0);
-  for (int sg = 0; sg < 2; ++sg) {
-    // sg 0: the source block column's panels before p;  sg 1: the previous block column
-    const int K = sg == 0 ? u.c0 : (u.s_off >= 0 ? u.s_k : 0);
-    if (K <= 0) continue;
-    const int sld = sg == 0 ? ld : u.s_ld;
-    const int rsh = sg == 0 ? 0 : u.s_rshift;
-    const double* base = L + (sg == 0 ? u.off : u.s_off);
-    const double* pa = base + (int64_t)(arow + rsh) * sld + lq;
-    const double* p0 = base + (int64_t)(b0row + rsh) * sld + lq;
-    const double* p1 = base + (int64_t)(b1row + rsh) * sld + lq;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-      double av[16], v0[16], v1[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int k = min(k0 + 4 * t, K - 4 + 3 - lq);   // stays inside the row: k + lq <= K - 1
-        av[t] = pa[k];
-        v0[t] = p0[k];
-        v1[t] = p1[k];
-      }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const bool kok = k0 + 4 * t + lq < K;
-        const double a = (aok && kok) ? av[t] : 0.0;
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (b0ok && kok) ? v0[t] : 0.0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (b1ok && kok) ? v1[t] : 0.0, acc[1], 0, 0, 0);
-      }
+      const int i = ib * 16 + lq + 4 * r, j = jb * 16 + lr;
+      if (i < pn && j < cq) W[(int64_t)i * ldw + j] = -(acc0[r] + acc1[r]);
     }
   }
-  double* Dst = L + u.d_off;
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + rf * 16 + lq + 4 * r, j = (cfb + c) * 16 + lr;
-      if (i < u.nrows && j < u.d_pn && i >= j)
-        unsafeAtomicAdd(Dst + (int64_t)(rb + i - u.d_rshift) * u.d_ld + u.d_c0 + j, -acc[c][r]);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -793,145 +725,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
 }
 
 // ---------------------------------------------------------------------------
-// a12 for all sub-diagonal rows of a block column in one launch: each
-// workgroup owns a strip of RS rows and runs the blocked substitution over the
-// block column's panels with the strip resident in LDS:
-//     X_p = (A_p - sum_{q<p} X_q L_pq^T) * inv(L_pp)^T ,   p = 0, 1, ...
-// L_pq (blocks of the factored diagonal tile) and inv(L_pp) (dinv scratch) are
-// staged through LDS; all products run on v_mfma_f64_16x16x4_f64, wave w owning
-// the 16-column tile w of the current panel.  Replaces the 2*np-1 dependent
-// TRSM/UPDATE launches per block column of the unfused path.
-// ---------------------------------------------------------------------------
-constexpr int SLD = 66;  // staging block row stride
-
-// 64 x 64 staging block: thread t fetches 16 consecutive doubles of row t/4
-// with all loads in flight at once (clamped addresses, zero-filled afterwards)
-__device__ inline void stage64(double* __restrict__ Ls, const double* __restrict__ src, int ld,
-                               int nrow, int ncol, int tid) {
-  const int j = tid >> 2, c = (tid & 3) * 16;
-  const int jc = j < nrow ? j : nrow - 1;
-  double v[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int k = c + e < ncol ? c + e : ncol - 1;
-    v[e] = src[(int64_t)jc * ld + k];
-  }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) Ls[j * SLD + c + e] = (j < nrow && c + e < ncol) ? v[e] : 0.0;
-}
-
-template <int RS, int WMAX>
-__global__ __launch_bounds__(256) void k_trsm_strip(const UpdTile* __restrict__ tiles,
-                                                    const StripUnit* __restrict__ units,
-                                                    double* __restrict__ L,
-                                                    const double* __restrict__ dinv) {
-  constexpr int XLD = WMAX + 2;
-  constexpr int RT = RS / 16;
-  constexpr int TPR = 256 / RS;          // threads per strip row
-  __shared__ double Xs[RS * XLD];
-  __shared__ double Ls[64 * SLD];
-  const UpdTile tl = tiles[blockIdx.x];
-  const StripUnit u = units[tl.unit];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int w = u.ld, pw = u.pw;
-  const int wpad = (w + 15) & ~15;
-  const int r0 = u.row0 + (int)tl.ti * RS;
-  const int nr = min(RS, u.row0 + u.nrows - r0);
-  double* A = L + u.off;
-  // strip load: thread t owns row t/TPR, 16-column chunks (t%TPR), (t%TPR)+TPR, ...
-  const int si = tid / TPR, sc = (tid % TPR) * 16;
-  {
-    const double* arow = A + (int64_t)(r0 + (si < nr ? si : nr - 1)) * w;
-    for (int c = sc; c < wpad; c += TPR * 16) {
-      double v[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = arow[c + e < w ? c + e : w - 1];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Xs[si * XLD + c + e] = (si < nr && c + e < w) ? v[e] : 0.0;
-    }
-    // A ragged last panel makes the 16-wide accumulator tiles and the K loop (steps of
-    // 4) read up to 63 columns past the block column.  Those operands meet zero
-    // factors, but stale LDS may hold NaN bit patterns and 0 * NaN poisons the whole
-    // output row (seen once as a spurious "not positive definite"): clear them.
-    for (int c = wpad + sc; c < min(wpad + 64, XLD); c += TPR * 16)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (c + e < XLD) Xs[si * XLD + c + e] = 0.0;
-  }
-  const int np = (w + pw - 1) / pw;
-  int64_t slot = u.dinv_off;
-  for (int p = 0; p < np; ++p) {
-    const int c0 = p * pw;
-    const int pn = min(pw, w - c0);
-    const bool act = wave * 16 < pn;   // this wave's 16-column tile exists in the panel
-    d4 acc[RT];
-    __syncthreads();                   // Xs complete (initial load / previous panel's X)
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      if (act) acc[rt] = ld_c_s<XLD>(Xs, rt * 16, c0 + wave * 16, lane);
-    for (int q = 0; q < p; ++q) {
-      __syncthreads();                 // previous staging block fully consumed
-      stage64(Ls, A + (int64_t)c0 * w + q * pw, w, pn, pw, tid);
-      __syncthreads();
-      if (act) {
-        for (int k = 0; k < pw; k += 4) {
-          const double b = Ls[(wave * 16 + lr) * SLD + k + lq];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const double a = -Xs[(rt * 16 + lr) * XLD + q * pw + k + lq];
-            acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rt], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // a panel whose width is not a multiple of 16 ends inside a wave's tile: the
-    // columns beyond it belong to the next panel and must not be touched
-    const bool colok = wave * 16 + lr < pn;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      if (act && colok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[(rt * 16 + lq + 4 * r) * XLD + c0 + wave * 16 + lr] = acc[rt][r];
-      }
-    // stage inv(L_pp), zero-padded to 64 x 64
-    stage64(Ls, dinv + slot, pn, pn, pn, tid);
-    __syncthreads();
-    d4 res[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) res[rt] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (act) {
-      const int kend = (pn + 3) & ~3;
-      for (int k = 0; k < kend; k += 4) {
-        const double b = Ls[(wave * 16 + lr) * SLD + k + lq];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const double a = Xs[(rt * 16 + lr) * XLD + c0 + k + lq];
-          res[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, res[rt], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();                   // every wave has read the panel before it is overwritten
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      if (act && colok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[(rt * 16 + lq + 4 * r) * XLD + c0 + wave * 16 + lr] = res[rt][r];
-      }
-    slot += (int64_t)pn * pn;
-  }
-  __syncthreads();
-  if (si < nr) {
-    double* arow = A + (int64_t)(r0 + si) * w;
-    for (int c = sc; c < w; c += TPR * 16) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (c + e < w) arow[c + e] = Xs[si * XLD + c + e];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // a26: extend-add of a generated element window into an ancestor tile,
 // dest[pos_r(i)][pos_c(j)] -= src[i][j]; positions found by binary search in
 // the destination's (sorted) index lists.
@@ -1055,8 +848,14 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
   for (int pp = 0; pp < np; ++pp) {
     const int p = BWD ? np - 1 - pp : pp;
     const int c0 = p * pw, pn = min(pw, w - c0);
-    int64_t slot = u.dinv_off + (int64_t)p * pw * pw;  // panels before p are full width
-    const double* D = dinv + slot;
+    // Winv of panel p (k_chain_panel): pn x (cq + pn), inv(L_pp) = its last pn columns
+    int64_t slot = u.dinv_off;
+    for (int t = 0; t < p; ++t) {
+      const int ct = t * pw, pt = min(pw, w - ct);
+      slot += (int64_t)pt * (ct % u.cb + pt);
+    }
+    const int ldw = c0 % u.cb + pn;
+    const double* D = dinv + slot + (ldw - pn);
     if (!BWD) {
       // rows of inv(L_pp) for the second half, requested before the first half's loads
       double dv[4][4];
@@ -1064,7 +863,7 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          dv[r][e] = D[(int64_t)min(rr + 16 * r, pn - 1) * pn + min(sub + 16 * e, pn - 1)];
+          dv[r][e] = D[(int64_t)min(rr + 16 * r, pn - 1) * ldw + min(sub + 16 * e, pn - 1)];
       // t_j = y_j - sum_{k<c0} L[c0+j][k] x_k
       if (c0 > 0) {
         double acc[4][NR];
@@ -1149,7 +948,7 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
         for (int k0 = wave; k0 < pn; k0 += 32) {
           double v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = D[min(k0 + 4 * e, pn - 1) * pn + cj];
+          for (int e = 0; e < 8; ++e) v[e] = D[(int64_t)min(k0 + 4 * e, pn - 1) * ldw + cj];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int k = k0 + 4 * e;
@@ -1308,10 +1107,54 @@ void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double*
   hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
 }
 
-void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, double* L,
-                       double* dinv, int* flag) {
+// dynamic LDS of k_chain_panel for sub-tiles with up to `max_rows_below` rows below a panel
+static unsigned chain_lds_bytes(int max_rows_below) {
+  const int urows = ((max_rows_below + 15) / 16) * 16;
+  const int extra = urows > 64 ? urows - 64 : 0;
+  return (unsigned)(sizeof(PotrfShared) + sizeof(double) * (size_t)extra * TLD);
+}
+
+void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, int max_rows_below,
+                        double* L, double* dinv, int* flag) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_tile_chain, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+  thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    (void)hipFuncSetAttribute((const void*)k_chain_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(k_chain_panel, dim3((unsigned)count), dim3(kChainThreads), chain_lds_bytes(max_rows_below),
+                     st, units, L, dinv, flag);
+}
+
+void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_winv, dim3((unsigned)count), dim3(kChainThreads), 0, st, units, L, dinv);
+}
+
+// debug aid (engine flag 128): one workgroup per CU-sized LDS allocation writes a
+// signalling-NaN pattern over all 160 KB, so that any kernel that later reads LDS it
+// has not written computes with NaNs instead of with whatever the previous kernel left
+__global__ __launch_bounds__(256) void k_poison_lds(int* sink) {
+  extern __shared__ __attribute__((aligned(16))) double poison_smem[];
+  const double snan = __longlong_as_double(0x7FF4DEADBEEF0001LL);
+  for (int i = threadIdx.x; i < 160 * 1024 / 8; i += 256) poison_smem[i] = snan;
+  __syncthreads();
+  if (sink && poison_smem[threadIdx.x] == 0.0) *sink = 1;   // keeps the stores alive
+}
+
+void launch_poison_lds(hipStream_t st) {
+  thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    (void)hipFuncSetAttribute((const void*)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), 160 * 1024, st, (int*)nullptr);
 }
 
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
@@ -1345,21 +1188,6 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
   else
     hipLaunchKernelGGL((k_update<32, 32, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
                        units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
-}
-
-void launch_panel_step(hipStream_t st, const UpdTile* tiles, int64_t count,
-                       const PanelStepUnit* units, double* L, const double* dinv) {
-  if (count <= 0) return;
-  hipLaunchKernelGGL(k_panel_step, dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
-}
-
-void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
-                  const StripUnit* units, double* L, const double* dinv) {
-  if (count <= 0) return;
-  if (rs == 32)
-    hipLaunchKernelGGL((k_trsm_strip<32, 320>), dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
-  else
-    hipLaunchKernelGGL((k_trsm_strip<16, 896>), dim3((unsigned)count), dim3(256), 0, st, tiles, units, L, dinv);
 }
 
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,

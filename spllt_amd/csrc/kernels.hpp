@@ -13,10 +13,14 @@ void launch_scatter_val(hipStream_t st, double* L, const double* val, const int6
                         const int64_t* src, int64_t n);
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag);
-// whole panel chain of one diagonal tile per workgroup (unit: off = block column,
-// ld = width, n = tile order (<= 256), flags = panel width)
-void launch_tile_chain(hipStream_t st, const PotrfUnit* units, int64_t count, double* L,
-                       double* dinv, int* flag);
+// one step of the panel chain per workgroup (ChainUnit); max_rows_below = most rows of a
+// sub-tile below a panel over the units of the launch (sizes the dynamic LDS)
+void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, int max_rows_below,
+                        double* L, double* dinv, int* flag);
+// W part of Winv of the same units (side stream)
+void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv);
+// debug: fill the LDS of every CU with signalling NaNs
+void launch_poison_lds(hipStream_t st);
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv, int prio = 0,
@@ -26,13 +30,6 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,
                           double* dest, int ldd);
 
-// fused TRSM + next-panel update (tiles: unit, ti = 32-row tile of the rows below the panel)
-void launch_panel_step(hipStream_t st, const UpdTile* tiles, int64_t count,
-                       const PanelStepUnit* units, double* L, const double* dinv);
-
-// rs = rows per strip: 32 (block column width <= 320) or 16 (<= 896)
-void launch_strip(hipStream_t st, int rs, const UpdTile* tiles, int64_t count,
-                  const StripUnit* units, double* L, const double* dinv);
 // one launch of the device solve (kind = SolveKind)
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,

@@ -40,7 +40,7 @@ struct OpsBatch {
     UpdUnit* d_units = nullptr;
     UpdTile* d_tiles = nullptr;
     PotrfUnit* d_potrf = nullptr;
-    StripUnit* d_strips = nullptr;
+    ChainUnit* d_chain = nullptr;
     double* d_dinv = nullptr;
     int* d_flag = dev_flag;
     bool own_flag = false;
@@ -59,7 +59,7 @@ struct OpsBatch {
     up((void**)&d_units, P.units.data(), P.units.size() * sizeof(UpdUnit));
     up((void**)&d_tiles, P.tiles.data(), P.tiles.size() * sizeof(UpdTile));
     up((void**)&d_potrf, P.potrf_units.data(), P.potrf_units.size() * sizeof(PotrfUnit));
-    up((void**)&d_strips, P.strip_units.data(), P.strip_units.size() * sizeof(StripUnit));
+    up((void**)&d_chain, P.chain_units.data(), P.chain_units.size() * sizeof(ChainUnit));
     if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * std::max<int64_t>(1, P.dinv_size));
     if (e == hipSuccess && !d_flag) {
       own_flag = true;
@@ -73,8 +73,10 @@ struct OpsBatch {
         if (l.count <= 0) continue;
         if (l.kind == L_POTRF)
           launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag);
-        else if (l.kind == L_STRIP)
-          launch_strip(st, l.tile, d_tiles + l.first, l.count, d_strips, base, d_dinv);
+        else if (l.kind == L_CHAIN)
+          launch_chain_panel(st, d_chain + l.first, l.count, l.tile, base, d_dinv, d_flag);
+        else if (l.kind == L_WINV)
+          launch_winv(st, d_chain + l.first, l.count, base, d_dinv);
         else
           launch_update(st, l.tile, d_tiles + l.first, l.count, d_units, d_off, d_w, base, relpos,
                         rlist, d_dinv);
@@ -83,7 +85,7 @@ struct OpsBatch {
       hipError_t e2 = hipStreamSynchronize(st);
       if (e == hipSuccess) e = e2;
     }
-    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_strips); hipFree(d_dinv);
+    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_chain); hipFree(d_dinv);
     if (own_flag) hipFree(d_flag);
     if (e != hipSuccess) {
       std::fprintf(stderr, "spllt-hip: operator failed: %s\n", hipGetErrorString(e));
@@ -141,7 +143,6 @@ int spllt_factor_diag_block_hip(void* stream, int m, int n, double* bc, int* dev
   OpsBatch B;
   ScheduleOptions so;
   so.lookahead = false;  // one stream, program order
-  so.panel_step = false; // the operator twins run the unfused POTRF / TRSM / UPDATE launches
   build_program(S, so, B.P);
   B.bc_off = {S.bcols[0].off};
   B.bc_w = {n};

@@ -10,7 +10,7 @@ namespace spx {
 namespace {
 
 struct Edge {
-  int stream = 0, wait0 = -1, wait1 = -1, record = -1, overlap = 0;
+  int stream = 0, wait0 = -1, wait1 = -1, wait2 = -1, record = -1, overlap = 0;
 };
 
 static int64_t env_int(const char* name, int64_t dflt) {
@@ -19,7 +19,6 @@ static int64_t env_int(const char* name, int64_t dflt) {
 }
 
 struct Builder {
-  bool level_atomic = false;  // DIRECT units of the current level must use atomics
   const Symbolic& S;
   const ScheduleOptions& opt;
   Program& P;
@@ -59,10 +58,10 @@ struct Builder {
     if (us.empty()) {
       // keep the event graph consistent: an empty phase still has to forward
       // its record event; emit a marker launch with no work
-      if (e.record >= 0 || e.wait0 >= 0 || e.wait1 >= 0) {
+      if (e.record >= 0 || e.wait0 >= 0 || e.wait1 >= 0 || e.wait2 >= 0) {
         Launch L;
         L.kind = L_GEMM; L.level = level; L.first = 0; L.count = 0; L.tile = 64; L.flops = 0;
-        L.stream = e.stream; L.wait0 = e.wait0; L.wait1 = e.wait1; L.record = e.record;
+        L.stream = e.stream; L.add_wait(e.wait0); L.add_wait(e.wait1); L.add_wait(e.wait2); L.record = e.record;
         P.launches.push_back(L);
       }
       return;
@@ -85,7 +84,6 @@ struct Builder {
     const bool tiny_launch = n64 > 0 && n64 <= tiny_max;
     for (auto& u : us) {
       int uid = (int)P.units.size();
-      if (u.mode == MODE_DIRECT) u.atomic = level_atomic ? 1 : 0;
       u.a_w = S.bcols[u.src_bcol0].width;
       u.a_off = S.bcols[u.src_bcol0].off;
       P.units.push_back(u);
@@ -143,8 +141,11 @@ struct Builder {
       L.tile = edges[pass];
       L.flops = flops * ((double)tv.size() * (edges[pass] / 32) * (edges[pass] / 32)) / std::max(1.0, ntot);
       L.stream = e.stream;
-      L.wait0 = pass == first_nonempty ? e.wait0 : -1;
-      L.wait1 = pass == first_nonempty ? e.wait1 : -1;
+      if (pass == first_nonempty) {
+        L.add_wait(e.wait0);
+        L.add_wait(e.wait1);
+        L.add_wait(e.wait2);
+      }
       L.record = pass == last_nonempty ? e.record : -1;
       L.overlap = e.overlap;
       P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
@@ -208,6 +209,7 @@ struct Builder {
           u.N = cptr2 - cptr + 1;
           u.k0 = 0;
           u.klen = -1;
+          u.dinv_ld = S.node_bcol0[a] + cb;   // (unused by the kernel in this mode) destination block column
           out.push_back(u);
           cptr = cptr2 + 1;
         }
@@ -252,30 +254,70 @@ struct Builder {
     return fl;
   }
 
+  // A DIRECT update unit: destination = columns [dc0, dc0+N) x stored rows [dr0, dr0+M) of block
+  // column D (global id bd), K = columns [k0, k0+klen) of block column bs of the same node.
+  UpdUnit direct_unit(int bs, int k0, int klen, int bd, int dr0, int M, int dc0, int N) const {
+    const BlockCol& B = S.bcols[bs];
+    const BlockCol& D = S.bcols[bd];
+    UpdUnit u{};
+    u.b_bcol0 = -1;
+    u.lower = 1;
+    u.mode = MODE_DIRECT;
+    u.d_off = D.off;
+    u.d_ld = D.width;
+    u.d_row0 = dr0;
+    u.d_col0 = dc0;
+    u.src_bcol0 = bs;
+    u.nseg = 1;
+    u.seg_r0 = B.r0;
+    u.seg_stride = nb;
+    u.src_r0 = D.r0 + dr0;   // node-local row of destination row dr0
+    u.src_c0 = D.r0 + dc0;   // node-local row that corresponds to destination column dc0
+    u.M = M;
+    u.N = N;
+    u.k0 = k0;
+    u.klen = klen;
+    return u;
+  }
+  static double direct_flops(const UpdUnit& u) {
+    // lower part only where the unit straddles the diagonal (src_r0 == src_c0)
+    const double full = (double)u.M * u.N;
+    const double cut = (u.src_r0 == u.src_c0) ? 0.5 * u.N * (u.N - 1) : 0.0;
+    return 2.0 * u.klen * (full - cut);
+  }
+
   void run() {
     P.pw = pw;
+    const int cb = std::max(pw, (std::max(opt.cb, pw) / pw) * pw);   // multiple of the panel width
+    P.cb = cb;
     const int nn = S.nnodes;
     int maxlevel = -1;
     for (int s = 0; s < nn; ++s) maxlevel = std::max(maxlevel, S.level[s]);
 
-    // dinv slots: one per (block column, panel)
+    // dinv slots: one Winv per (block column, panel), see ChainUnit
     std::vector<int64_t> dinv_slot(S.nbcol() + 1, 0);
     {
       int64_t o = 0;
       for (int b = 0; b < S.nbcol(); ++b) {
         dinv_slot[b] = o;
-        int w = S.bcols[b].width;
-        for (int c = 0; c < w; c += pw) {
-          int pn = std::min(pw, w - c);
-          o += (int64_t)pn * pn;
-        }
+        const int w = S.bcols[b].width;
+        o += winv_offset(w, pw, cb, cdiv(w, pw));
       }
       dinv_slot[S.nbcol()] = o;
       P.dinv_size = o;
     }
 
+    const bool la = opt.lookahead;
+    const bool soc = opt.side_on_chain;
+    auto edge = [&](int stream) {
+      Edge e;
+      e.stream = (!la || (soc && stream == ST_SIDE)) ? ST_CHAIN : stream;
+      return e;
+    };
     std::vector<UpdUnit> us;
-    int ev_level = -1;  // completion event of the previous level
+    int ev_level = -1;       // event that covers everything of the levels processed so far
+    std::vector<std::pair<int, int>> zone_events;  // (zone, event) of the last level's inter-node updates
+    bool zoned = false;      // ... and they were really split into zones
     // A partitioned program (multi-GPU) runs the rank's own subtrees first, then
     // an EXCHANGE marker (the extend-add of the top-tree block columns across
     // ranks happens there), then the replicated top tree.
@@ -295,11 +337,13 @@ struct Builder {
       X.first = X.count = 0;
       X.tile = 0;
       X.flops = 0;
-      X.stream = 0;
-      X.wait0 = ev_level;  // everything of phase 1, both streams
+      X.stream = ST_CHAIN;
+      X.add_wait(ev_level);  // everything of phase 1, all streams
       int ev = P.nevents++;
       X.record = ev;
       ev_level = ev;
+      zone_events.clear();
+      zone_events.push_back({0, ev});   // phase 2 starts behind the exchange
       P.launches.push_back(X);
     }
     for (int lev = 0; lev <= maxlevel; ++lev) {
@@ -307,484 +351,299 @@ struct Builder {
       if (nodes.empty()) continue;
       int maxnc = 0;
       for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
-      const bool la = opt.lookahead;
-      bool first_of_level = true;   // first panel-stream launch waits for the previous level
-      int evB_prev = -1;            // bulk event of step c-1 (trailing update of c-1 -> c+1..)
-      int evP_last = -1;            // panel event of the last finished step
-      int evB1_prev = -1;           // bulk event: rest rows of block column c updated by c-1
-      // The fused strip kernel shortens the panel chain (1 launch instead of
-      // 2*np-1 per block column) but runs one workgroup per CU; it pays where
-      // the level is latency-bound (few, large nodes), not where thousands of
-      // strips would queue.  Use it when all strips of a step fit in ~2 rounds.
-      std::vector<int> evB_hist;    // bulk event of every step of this level
-      bool fs = la && opt.fused_strip;
-      if (fs) {
-        int64_t worst = 0;
-        for (int c = 0; c < maxnc; ++c) {
-          int64_t strips = 0;
-          for (int s : nodes) {
-            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-            if (c >= nc) continue;
-            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
-            if (B.nrow > B.width) strips += cdiv(B.nrow - B.width, B.width <= 320 ? 32 : 16);
-          }
-          worst = std::max(worst, strips);
-        }
-        fs = worst <= opt.strip_limit;
-      }
-      // fused panel steps (k_panel_step): TRSM + every missing update of the next
-      // 64-wide panel in one launch, on levels whose steps are latency-bound
-      bool ps = !fs && opt.panel_step;
-      if (ps) {
-        int64_t worst = 0;
-        for (int c = 0; c < maxnc; ++c) {
-          int64_t t = 0;
-          for (int s : nodes) {
-            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-            if (c >= nc) continue;
-            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
-            t += cdiv(std::max(0, B.nrow - std::min(pw, B.width)), 32);
-          }
-          worst = std::max(worst, t);
-        }
-        ps = worst <= opt.panel_step_limit;
-      }
+      // Zones: the inter-node updates at the end of the previous level were issued sorted by
+      // destination -- first everything that lands in block column 0 of the nodes of THIS level,
+      // then block column 1, ... -- with an event per zone (zone_events).  Step c of this level
+      // only waits for zone c, so the panel chains of a level run beside the bulk of the
+      // inter-node updates of the level below instead of after it.  zev(c): the event that
+      // covers every update into block column c of this level's nodes.
+      const std::vector<std::pair<int, int>> zones_in = zone_events;
+      auto zev = [&](int c) {
+        int ev = -1;
+        for (const auto& z : zones_in)
+          if (z.first <= c) ev = z.second;
+        return ev;
+      };
+      const bool pipelined = la && zoned;   // zones of the level below may still be running
+      std::vector<int> evB_hist;    // bulk event of every step of this level (-1: none)
+      int evD_last = -1;            // "block column done" event of the last finished chunk
+      int evF_last = -1;            // last far-stream event (early inter-node slices)
       // inter-node update units of every node of the level (all K segments); they
       // are issued in slices as the block columns they read become final
       std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
       std::vector<int> emitted(nodes.size(), 0);
       for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
-      int evF_last = -1;            // last far-stream event (early inter-node slices)
-      const bool lazy = la && !fs && !ps && opt.lazy_next;
-      // merged / fused panel updates share destinations with concurrently running launches
-      level_atomic = lazy || ps;
       for (int c = 0; c < maxnc; ++c) {
-        int maxp = 0;
+        int maxw = 0;
         for (int s : nodes) {
-          int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-          if (c < nc) maxp = std::max(maxp, cdiv(S.bcols[S.node_bcol0[s] + c].width, pw));
+          const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+          if (c < nc) maxw = std::max(maxw, S.bcols[S.node_bcol0[s] + c].width);
         }
-        // With the fused strip kernel the panel chain only walks the diagonal
-        // tile (rows < width); the rows below are solved by one k_trsm_strip
-        // launch once every panel of the tile is factored.
-        auto chain_rows = [&](const BlockCol& B) {
-          return (fs && B.width <= 896) ? std::min(B.nrow, B.width) : B.nrow;
-        };
-        // (0) single-workgroup panel chain of the diagonal tiles (fused mode, w <= 256)
-        bool chained = false;
-        // (k_tile_chain walks K in steps of 4 and 16-column tiles: panel widths that are
-        // no multiple of 16 keep the per-panel launches)
-        if (fs && opt.tile_chain && pw % 16 == 0) {
-          bool all_fit = true;
+        const int ng = cdiv(maxw, cb);
+        const int evB_c2 = (la && c >= 2) ? evB_hist[c - 2] : -1;   // bulk (c-2 -> c..)
+        const int evB_c1 = (la && c >= 1) ? evB_hist[c - 1] : -1;   // bulk (c-1 -> c+1..)
+        for (int g = 0; g < ng; ++g) {
+          const int cs = g * cb;
+          int maxq = 0;
           for (int s : nodes) {
-            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-            if (c < nc && S.bcols[S.node_bcol0[s] + c].width > 256) all_fit = false;
+            const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c >= nc) continue;
+            const int w = S.bcols[S.node_bcol0[s] + c].width;
+            if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pw));
           }
-          if (all_fit) {
-            Launch L;
-            L.kind = L_CHAIN;
-            L.level = lev;
-            L.first = (int64_t)P.chain_units.size();
-            L.tile = 0;
-            double fl = 0;
-            for (int s : nodes) {
-              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              int b = S.node_bcol0[s] + c;
-              const BlockCol& B = S.bcols[b];
-              PotrfUnit q{};
-              q.off = B.off;
-              q.dinv_off = dinv_slot[b];
-              q.ld = B.width;
-              q.n = std::min(B.nrow, B.width);
-              q.gcol = S.sptr[s] + B.r0;
-              q.flags = pw;
-              P.chain_units.push_back(q);
-              fl += (double)q.n * q.n * q.n / 3.0;
-            }
-            L.count = (int64_t)P.chain_units.size() - L.first;
-            L.flops = fl;
-            P.flops_potrf += fl;
-            if (first_of_level) {
-              L.wait0 = ev_level;
-              first_of_level = false;
-            }
-            if (L.count > 0) P.launches.push_back(L);
-            chained = true;
-          }
-        }
-        for (int p = 0; p < maxp && !chained; ++p) {
-          // (1) left-looking update of panel p by the previous panels of the block
-          // column and (lazy_next) by the previous block column of the node
-          double fl = 0;
-          if (!ps && (p > 0 || (lazy && c > 0))) {
-            for (int s : nodes) {
-              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              int b = S.node_bcol0[s] + c;
-              const BlockCol& B = S.bcols[b];
-              int c0 = p * pw;
-              if (c0 >= B.width) continue;
-              int pn = std::min(pw, B.width - c0);
-              if (lazy && c > 0) {
-                const BlockCol& Q = S.bcols[b - 1];
-                UpdUnit v{};
-                v.b_bcol0 = -1;
-                v.lower = 1;
-                v.mode = MODE_DIRECT;
-                v.d_off = B.off;
-                v.d_ld = B.width;
-                v.d_row0 = c0;
-                v.d_col0 = c0;
-                v.src_bcol0 = b - 1;
-                v.nseg = 1;
-                v.seg_r0 = Q.r0;
-                v.seg_stride = nb;
-                v.src_r0 = B.r0 + c0;
-                v.src_c0 = B.r0 + c0;
-                v.M = B.nrow - c0;
-                v.N = pn;
-                v.k0 = 0;
-                v.klen = Q.width;
-                us.push_back(v);
-                fl += 2.0 * Q.width * ((double)v.M * pn - 0.5 * pn * (pn - 1));
+          int evCH = -1;
+          for (int q = 0; q < maxq; ++q) {
+            // (1) chain step: panel q of the sub-tile, one workgroup per node
+            {
+              Launch L;
+              L.kind = L_CHAIN;
+              L.level = lev;
+              L.first = (int64_t)P.chain_units.size();
+              L.tile = 0;
+              double fl = 0;
+              for (int s : nodes) {
+                const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+                if (c >= nc) continue;
+                const int b = S.node_bcol0[s] + c;
+                const BlockCol& B = S.bcols[b];
+                const int c0 = cs + q * pw;
+                if (c0 >= std::min(B.width, cs + cb)) continue;
+                const int ce = std::min(B.width, cs + cb);
+                const int pn = std::min(pw, ce - c0);
+                ChainUnit u{};
+                u.off = B.off;
+                u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
+                u.ld = B.width;
+                u.c0 = c0;
+                u.pn = pn;
+                u.cs = cs;
+                u.ce = ce;
+                u.gcol = S.sptr[s] + B.r0 + c0;
+                P.chain_units.push_back(u);
+                const int below = ce - c0 - pn;
+                L.tile = std::max(L.tile, below);
+                const double fp = (double)pn * pn * pn / 3.0, ft = (double)below * pn * pn;
+                const double fu = (double)pn * ((double)below * (below + 1));
+                P.flops_potrf += fp;
+                P.flops_trsm += ft;
+                P.flops_update += fu;
+                fl += fp + ft + fu;
               }
-              if (p == 0) continue;
+              L.count = (int64_t)P.chain_units.size() - L.first;
+              L.flops = fl;
+              L.stream = ST_CHAIN;
+              if (la) {
+                if (g == 0 && q == 0) {
+                  L.add_wait(zev(c));    // every inter-node update into block column c
+                  L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
+                }
+                evCH = P.nevents++;
+                L.record = evCH;
+              }
+              if (L.count > 0) P.launches.push_back(L);
+            }
+            // (2) rows below the sub-tile: X = [X(:, cs:c0) | A(:, c0:c0+pn)] Winv^T, after the
+            // W part of Winv (k_winv, side stream) for the units that have such rows
+            double fl = 0;
+            if (q > 0) {
+              Launch L;
+              L.kind = L_WINV;
+              L.level = lev;
+              L.first = (int64_t)P.chain_units.size();
+              L.tile = 0;
+              for (int s : nodes) {
+                const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+                if (c >= nc) continue;
+                const int b = S.node_bcol0[s] + c;
+                const BlockCol& B = S.bcols[b];
+                const int c0 = cs + q * pw;
+                if (c0 >= std::min(B.width, cs + cb)) continue;
+                const int ce = std::min(B.width, cs + cb);
+                if (B.nrow - ce <= 0) continue;
+                ChainUnit u{};
+                u.off = B.off;
+                u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
+                u.ld = B.width;
+                u.c0 = c0;
+                u.pn = std::min(pw, ce - c0);
+                u.cs = cs;
+                u.ce = ce;
+                u.gcol = S.sptr[s] + B.r0 + c0;
+                P.chain_units.push_back(u);
+              }
+              L.count = (int64_t)P.chain_units.size() - L.first;
+              L.flops = 0;
+              L.stream = (la && !soc) ? ST_SIDE : ST_CHAIN;
+              if (la && !soc) L.add_wait(evCH);
+              if (L.count > 0) P.launches.push_back(L);
+            }
+            for (int s : nodes) {
+              const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              const int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              const int c0 = cs + q * pw;
+              if (c0 >= std::min(B.width, cs + cb)) continue;
+              const int ce = std::min(B.width, cs + cb);
+              const int pn = std::min(pw, ce - c0);
+              const int rows = B.nrow - ce;
+              if (rows <= 0) continue;
               UpdUnit u{};
               u.b_bcol0 = -1;
-              u.lower = 1;
-              u.mode = MODE_DIRECT;
+              u.mode = MODE_TRSM;
+              u.lower = 0;
               u.d_off = B.off;
               u.d_ld = B.width;
-              u.d_row0 = c0;
+              u.d_row0 = ce;
               u.d_col0 = c0;
               u.src_bcol0 = b;
               u.nseg = 1;
               u.seg_r0 = B.r0;
               u.seg_stride = nb;
-              u.src_r0 = B.r0 + c0;
-              u.src_c0 = B.r0 + c0;
-              u.M = chain_rows(B) - c0;
+              u.src_r0 = B.r0 + ce;
+              u.src_c0 = 0;
+              u.M = rows;
               u.N = pn;
-              u.k0 = 0;
-              u.klen = c0;
+              u.k0 = cs;
+              u.klen = c0 - cs + pn;
+              u.dinv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
+              u.dinv_ld = c0 - cs + pn;
               us.push_back(u);
-              fl += 2.0 * c0 * ((double)u.M * pn - 0.5 * pn * (pn - 1));
-            }
-            P.flops_update += fl;
-            Edge e1;
-            // the first launch of step c follows the bulk update (c-2 -> c..)
-            if (lazy && p == 0 && c >= 2) e1.wait0 = evB_hist[c - 2];
-            emit_gemm(lev, us, fl, true, e1);
-          }
-          // (2) POTRF of the diagonal panel blocks
-          {
-            Launch L;
-            L.kind = L_POTRF;
-            L.level = lev;
-            L.first = (int64_t)P.potrf_units.size();
-            L.tile = 0;
-            fl = 0;
-            for (int s : nodes) {
-              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              int b = S.node_bcol0[s] + c;
-              const BlockCol& B = S.bcols[b];
-              int c0 = p * pw;
-              if (c0 >= B.width) continue;
-              int pn = std::min(pw, B.width - c0);
-              PotrfUnit q{};
-              q.off = B.off + (int64_t)c0 * B.width + c0;
-              q.ld = B.width;
-              q.n = pn;
-              q.gcol = S.sptr[s] + B.r0 + c0;
-              int64_t slot = dinv_slot[b];
-              for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
-              q.dinv_off = slot;
-              P.potrf_units.push_back(q);
-              fl += (double)pn * pn * pn / 3.0;
-            }
-            L.count = (int64_t)P.potrf_units.size() - L.first;
-            L.flops = fl;
-            P.flops_potrf += fl;
-            if (la && first_of_level) {
-              L.wait0 = ev_level;  // everything of the previous level (incl. its bulk stream)
-              first_of_level = false;
-            } else if (la && ps && p == 0 && c >= 2) {
-              L.wait0 = evB_hist[c - 2];  // bulk update (c-2 -> c..) precedes the first panel of c
-            }
-            if (L.count > 0) P.launches.push_back(L);
-          }
-          // (3p) fused panel step: TRSM of the rows below + update of the next panel
-          if (ps) {
-            Launch L;
-            L.kind = L_PANEL;
-            L.level = lev;
-            L.first = (int64_t)P.tiles.size();
-            L.tile = 32;
-            fl = 0;
-            for (int s : nodes) {
-              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              int b = S.node_bcol0[s] + c;
-              const BlockCol& B = S.bcols[b];
-              int c0 = p * pw;
-              if (c0 >= B.width) continue;
-              int pn = std::min(pw, B.width - c0);
-              int rows = B.nrow - (c0 + pn);
-              if (rows <= 0) continue;
-              PanelStepUnit q{};
-              q.off = B.off;
-              q.ld = B.width;
-              q.c0 = c0;
-              q.pn = pn;
-              q.nrows = rows;
-              int64_t slot = dinv_slot[b];
-              for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
-              q.dinv_off = slot;
-              q.d_off = -1;
-              q.s_off = -1;
-              double kk = 0;  // K extent of the update (global segments + the panel)
-              if (c0 + pn < B.width) {
-                // next panel in the same block column: previous block column + own panels
-                q.d_off = B.off;
-                q.d_ld = B.width;
-                q.d_c0 = c0 + pn;
-                q.d_pn = std::min(pw, B.width - (c0 + pn));
-                q.d_rshift = 0;
-                kk = c0 + pn;
-                if (c > 0) {
-                  const BlockCol& Q = S.bcols[b - 1];
-                  q.s_off = Q.off;
-                  q.s_ld = Q.width;
-                  q.s_k = Q.width;
-                  q.s_rshift = Q.width;
-                  kk += Q.width;
-                }
-              } else if (c + 1 < nc) {
-                // panel 0 of the next block column: this block column's panels
-                const BlockCol& Dn = S.bcols[b + 1];
-                q.d_off = Dn.off;
-                q.d_ld = Dn.width;
-                q.d_c0 = 0;
-                q.d_pn = std::min(pw, Dn.width);
-                q.d_rshift = B.width;
-                kk = c0 + pn;
-              }
-              int uid = (int)P.panel_units.size();
-              P.panel_units.push_back(q);
-              for (int t = 0; t < cdiv(rows, 32); ++t) {
-                UpdTile tt;
-                tt.unit = uid;
-                tt.ti = (short)t;
-                tt.tj = 0;
-                P.tiles.push_back(tt);
-              }
-              const double ft = (double)rows * pn * pn;
-              double fu = 0;
-              if (q.d_off >= 0) fu = 2.0 * kk * ((double)rows * q.d_pn - 0.5 * q.d_pn * (q.d_pn - 1));
+              const double ft = (double)rows * pn * pn, fu = 2.0 * rows * pn * (c0 - cs);
               P.flops_trsm += ft;
               P.flops_update += fu;
               fl += ft + fu;
             }
-            L.count = (int64_t)P.tiles.size() - L.first;
-            L.flops = fl;
-            if (L.count > 0) P.launches.push_back(L);
-            continue;
+            if (!us.empty()) {
+              Edge e = edge(ST_SIDE);
+              if (la && !soc) e.wait0 = evCH;
+              emit_gemm(lev, us, fl, false, e);
+            }
           }
-          // (3) TRSM of the rows below the panel: X = A * inv(Lpp)^T (in place)
-          fl = 0;
+          // (3) the chunk is final once the side stream has seen its last chain step
+          int evD = -1;
+          if (la) {
+            Launch M;
+            M.kind = L_GEMM; M.level = lev; M.first = 0; M.count = 0; M.tile = 64; M.flops = 0;
+            M.stream = soc ? ST_CHAIN : ST_SIDE;
+            if (!soc) M.add_wait(evCH);
+            evD = P.nevents++;
+            M.record = evD;
+            P.launches.push_back(M);
+            evD_last = evD;
+          }
+          // (4) updates by the finished chunk.  The next diagonal sub-tile gates the
+          // chain (chain stream); the rest of the near zone -- the remainder of this
+          // block column, or of block column c+1 after the last chunk -- goes to the
+          // side stream; block columns c+2.. to the bulk stream, where they overlap
+          // the chain of block column c+1.
+          std::vector<UpdUnit> us_n1, us_n2, us_bulk;
+          double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0;
+          bool to_next_bcol = false;
           for (int s : nodes) {
-            int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
             if (c >= nc) continue;
-            int b = S.node_bcol0[s] + c;
+            const int b = S.node_bcol0[s] + c;
             const BlockCol& B = S.bcols[b];
-            int c0 = p * pw;
-            if (c0 >= B.width) continue;
-            int pn = std::min(pw, B.width - c0);
-            int rows = chain_rows(B) - (c0 + pn);
-            if (rows <= 0) continue;
-            UpdUnit u{};
-            u.b_bcol0 = -1;
-            u.mode = MODE_TRSM;
-            u.lower = 0;
-            u.d_off = B.off;
-            u.d_ld = B.width;
-            u.d_row0 = c0 + pn;
-            u.d_col0 = c0;
-            u.src_bcol0 = b;
-            u.nseg = 1;
-            u.seg_r0 = B.r0;
-            u.seg_stride = nb;
-            u.src_r0 = B.r0 + c0 + pn;
-            u.src_c0 = 0;
-            u.M = rows;
-            u.N = pn;
-            u.k0 = c0;
-            u.klen = pn;
-            int64_t slot = dinv_slot[b];
-            for (int cc = 0; cc < c0; cc += pw) slot += (int64_t)pw * pw;
-            u.dinv_off = slot;
-            u.dinv_ld = pn;
-            us.push_back(u);
-            fl += (double)rows * pn * pn;
-          }
-          P.flops_trsm += fl;
-          emit_gemm(lev, us, fl, false);
-        }
-        // (3s) fused strip TRSM of all rows below the diagonal tile
-        if (fs) {
-          for (int rs : {32, 16}) {
-            Launch L;
-            L.kind = L_STRIP;
-            L.level = lev;
-            L.first = (int64_t)P.tiles.size();
-            L.tile = rs;
-            double fl = 0;
-            for (int s : nodes) {
-              int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              int b = S.node_bcol0[s] + c;
-              const BlockCol& B = S.bcols[b];
-              if (B.width > 896 || B.nrow <= B.width) continue;
-              if ((B.width <= 320 ? 32 : 16) != rs) continue;
-              StripUnit q{};
-              q.off = B.off;
-              q.dinv_off = dinv_slot[b];
-              q.ld = B.width;
-              q.row0 = B.width;
-              q.nrows = B.nrow - B.width;
-              q.pw = pw;
-              int uid = (int)P.strip_units.size();
-              P.strip_units.push_back(q);
-              for (int t = 0; t < cdiv(q.nrows, rs); ++t) {
-                UpdTile tt;
-                tt.unit = uid;
-                tt.ti = (short)t;
-                tt.tj = 0;
-                P.tiles.push_back(tt);
+            if (cs >= B.width) continue;
+            const int ce = std::min(B.width, cs + cb);
+            if (ce < B.width) {
+              // inside the block column: K = this chunk
+              const int ce2 = std::min(B.width, ce + cb);
+              if (soc) {
+                // one launch, left-looking: only the next chunk's columns, by everything before
+                // them (K = [0, ce)): the launch stays small enough for the reserved CUs
+                UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
+                us_n1.push_back(n1);
+                fl_n1 += direct_flops(n1);
+                continue;
               }
-              fl += (double)q.nrows * B.width * B.width;
-            }
-            L.count = (int64_t)P.tiles.size() - L.first;
-            L.flops = fl;
-            L.stream = 0;
-            L.wait0 = evB1_prev;  // the rest rows were last written by the bulk stream
-            P.flops_trsm += fl;
-            if (L.count > 0) P.launches.push_back(L);
-          }
-        }
-        // (4) right-looking update of the node's later block columns, K = blkn.
-        // With lookahead the part that gates the next panel chain stays on the
-        // panel stream (block column c+1, or only its diagonal tile when the
-        // strip kernel is used) and the rest goes to the bulk stream, where it
-        // overlaps the panel chain of block column c+1.
-        int evP = -1;
-        if (la) {
-          evP = P.nevents++;
-          P.launches.back().record = evP;  // last launch of the panel chain of step c
-          evP_last = evP;
-        }
-        std::vector<UpdUnit> us_bulk, us_rest;
-        double fl = 0, fl_bulk = 0, fl_rest = 0;
-        for (int s : nodes) {
-          int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-          if (c + 1 >= nc) continue;
-          int b = S.node_bcol0[s] + c;
-          const BlockCol& B = S.bcols[b];
-          for (int jj = c + 1; jj < nc; ++jj) {
-            const BlockCol& D = S.bcols[S.node_bcol0[s] + jj];
-            UpdUnit u{};
-            u.b_bcol0 = -1;
-            u.lower = 1;
-            u.mode = MODE_DIRECT;
-            u.d_off = D.off;
-            u.d_ld = D.width;
-            u.d_row0 = 0;
-            u.d_col0 = 0;
-            u.src_bcol0 = b;
-            u.nseg = 1;
-            u.seg_r0 = B.r0;
-            u.seg_stride = nb;
-            u.src_r0 = D.r0;
-            u.src_c0 = D.r0;
-            u.M = D.nrow;
-            u.N = D.width;
-            u.k0 = 0;
-            u.klen = B.width;
-            const double f1 = 2.0 * B.width * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
-            if ((lazy || ps) && jj == c + 1) {
-              continue;  // applied panel by panel in step c+1
-            } else if (la && jj > c + 1) {
-              us_bulk.push_back(u);
-              fl_bulk += f1;
-            } else if (fs && jj == c + 1 && D.width <= 896 && D.nrow > D.width) {
-              // split: diagonal tile of block column c+1 (panel stream) / rows below (bulk)
-              UpdUnit ud = u, ur = u;
-              ud.M = D.width;
-              ur.d_row0 = D.width;
-              ur.src_r0 = D.r0 + D.width;
-              ur.M = D.nrow - D.width;
-              const double fd = 2.0 * B.width * ((double)ud.M * ud.N - 0.5 * ud.N * (ud.N - 1));
-              us.push_back(ud);
-              fl += fd;
-              us_rest.push_back(ur);
-              fl_rest += f1 - fd;
+              UpdUnit n1 = direct_unit(b, cs, ce - cs, b, ce, ce2 - ce, ce, ce2 - ce);
+              us_n1.push_back(n1);
+              fl_n1 += direct_flops(n1);
+              if (B.nrow > ce2) {
+                UpdUnit n2 = direct_unit(b, cs, ce - cs, b, ce2, B.nrow - ce2, ce, B.width - ce);
+                us_n2.push_back(n2);
+                fl_n2 += direct_flops(n2);
+              }
             } else {
-              us.push_back(u);
-              fl += f1;
+              // last chunk: the whole block column updates the node's later block columns
+              for (int jj = c + 1; jj < nc; ++jj) {
+                const int bd = S.node_bcol0[s] + jj;
+                const BlockCol& D = S.bcols[bd];
+                if (jj == c + 1) {
+                  to_next_bcol = true;
+                  const int ce0 = soc ? D.nrow : std::min(cb, D.width);
+                  if (soc) {   // one launch: the whole next block column
+                    UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
+                    us_n1.push_back(n1);
+                    fl_n1 += direct_flops(n1);
+                    continue;
+                  }
+                  UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, ce0, 0, ce0);
+                  us_n1.push_back(n1);
+                  fl_n1 += direct_flops(n1);
+                  if (D.nrow > ce0) {
+                    UpdUnit n2 = direct_unit(b, 0, B.width, bd, ce0, D.nrow - ce0, 0, D.width);
+                    us_n2.push_back(n2);
+                    fl_n2 += direct_flops(n2);
+                  }
+                } else {
+                  UpdUnit u = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
+                  // zones of the level below may still be adding into this block column
+                  if (pipelined) u.atomic = 1;
+                  (la ? us_bulk : us_n2).push_back(u);
+                  (la ? fl_bulk : fl_n2) += direct_flops(u);
+                }
+              }
             }
           }
-        }
-        P.flops_update += fl + fl_bulk + fl_rest;
-        if (!la) {
-          emit_gemm(lev, us, fl);
-        } else {
-          Edge e0;  // c -> c+1 on the panel stream, after the bulk update (c-1 -> c+1..)
-          e0.stream = 0;
-          e0.wait0 = evB_prev;
-          if (!us.empty()) emit_gemm(lev, us, fl, true, e0);
-          int evB1 = -1;
-          bool waited = false;
-          if (!us_rest.empty()) {
-            Edge e1;
-            e1.stream = 1;
-            e1.overlap = 1;
-            e1.wait0 = evP;
-            waited = true;
-            evB1 = P.nevents++;
-            e1.record = evB1;
-            emit_gemm(lev, us_rest, fl_rest, true, e1);
+          P.flops_update += fl_n1 + fl_n2 + fl_bulk;
+          if (!us_n1.empty()) {
+            Edge e = edge(ST_CHAIN);
+            if (la) {
+              e.wait0 = evD;
+              if (to_next_bcol) {
+                e.wait1 = evB_c1;      // bulk (c-1 -> c+1..) writes the same entries
+                e.wait2 = zev(c + 1);  // and so do the inter-node updates into block column c+1
+              }
+            }
+            emit_gemm(lev, us_n1, fl_n1, true, e);
           }
-          int evB = -1;
-          if (!us_bulk.empty()) {
-            Edge e1;
-            e1.stream = 1;
-            e1.overlap = 1;
-            e1.wait0 = waited ? -1 : evP;
-            evB = P.nevents++;
-            e1.record = evB;
-            emit_gemm(lev, us_bulk, fl_bulk, true, e1);
+          if (!us_n2.empty()) {
+            Edge e = edge(ST_SIDE);
+            if (la && to_next_bcol) {
+              e.wait0 = evB_c1;
+              e.wait1 = zev(c + 1);
+            }
+            emit_gemm(lev, us_n2, fl_n2, true, e);
           }
-          evB_prev = evB;
-          evB1_prev = evB1;
-          evB_hist.push_back(evB);
-          // (4b) early inter-node slices: block columns 0..c are final, so the part
-          // of update_between that reads them can run beside the remaining panel
-          // chains of the level (far stream) instead of after the last one
-          if (opt.slice_between && c + 1 < maxnc) {
-            std::vector<UpdUnit> sl;
-            double fs_ = collect_between(nodes, tmpl, emitted, c + 1, false, sl);
-            if (!sl.empty()) {
-              P.flops_between += fs_;
-              Edge ef;
-              ef.stream = 2;
-              ef.wait0 = evP;
-              static const int slice_pad = (int)env_int("SPLLT_SLICE_PAD", 0);
-              ef.overlap = slice_pad;
-              evF_last = P.nevents++;
-              ef.record = evF_last;
-              emit_gemm(lev, sl, fs_, true, ef);
+          if (g + 1 == ng) {
+            int evB = -1;
+            if (!us_bulk.empty()) {
+              Edge e = edge(ST_BULK);
+              e.overlap = 1;
+              e.wait0 = evD;
+              evB = P.nevents++;
+              e.record = evB;
+              emit_gemm(lev, us_bulk, fl_bulk, true, e);
+            }
+            evB_hist.push_back(evB);
+            // (4b) early inter-node slices: block columns 0..c are final, so the part
+            // of update_between that reads them can run beside the remaining panel
+            // chains of the level (far stream) instead of after the last one
+            if (la && opt.slice_between && c + 1 < maxnc) {
+              std::vector<UpdUnit> sl;
+              double fs_ = collect_between(nodes, tmpl, emitted, c + 1, false, sl);
+              if (!sl.empty()) {
+                P.flops_between += fs_;
+                Edge ef = edge(ST_FAR);
+                ef.wait0 = evD;
+                ef.overlap = 1;
+                evF_last = P.nevents++;
+                ef.record = evF_last;
+                emit_gemm(lev, sl, fs_, true, ef);
+              }
             }
           }
         }
@@ -794,20 +653,57 @@ struct Builder {
       // issued during the panel chains have not covered yet
       std::vector<UpdUnit> rest;
       double fl = collect_between(nodes, tmpl, emitted, INT_MAX, true, rest);
-      us.insert(us.end(), rest.begin(), rest.end());
       P.flops_between += fl;
+      zone_events.clear();
+      zoned = false;
       if (!la) {
-        emit_gemm(lev, us, fl);
+        emit_gemm(lev, rest, fl);
       } else {
-        // bulk stream, after the last panel chain of the level; its completion
-        // event gates the first panel launch of the next level
-        Edge e;
-        e.stream = 1;
-        e.wait0 = evP_last;
-        e.wait1 = evF_last;   // early slices on the far stream
-        ev_level = P.nevents++;
-        e.record = ev_level;
-        emit_gemm(lev, us, fl, true, e);
+        // far stream, sorted by destination zone (see above); the event of the last zone
+        // covers the whole level
+        static const int zones_env = (int)env_int("SPLLT_ZONES", -1);
+        const bool use_zones = zones_env >= 0 ? zones_env != 0 : opt.zones;
+        auto zone_of = [&](const UpdUnit& u) {
+          const int a = S.bcols[u.dinv_ld].node;
+          if (!use_zones) return 0;   // one zone: every step of the next level waits for all of it
+          if (S.level[a] != lev + 1) return INT_MAX;
+          return u.dinv_ld - S.node_bcol0[a];
+        };
+        std::stable_sort(rest.begin(), rest.end(),
+                         [&](const UpdUnit& x, const UpdUnit& y) { return zone_of(x) < zone_of(y); });
+        {
+          // marker: the early slices of this level (they may already have covered a whole
+          // zone) and the zones of the level below are done -- what a step of the next level
+          // waits for when no zone of this level is left for its block column
+          std::vector<UpdUnit> none;
+          Edge e = edge(ST_FAR);
+          e.wait0 = evD_last;   // every block column of the level is final
+          e.wait1 = evF_last;   // early slices
+          e.wait2 = ev_level;   // the zones of the level below
+          ev_level = P.nevents++;
+          e.record = ev_level;
+          emit_gemm(lev, none, 0.0, true, e);
+          zone_events.push_back({-1, ev_level});
+        }
+        size_t i = 0;
+        while (i < rest.size()) {
+          const int z = zone_of(rest[i]);
+          std::vector<UpdUnit> grp;
+          double fz = 0;
+          for (; i < rest.size() && zone_of(rest[i]) == z; ++i) {
+            const UpdUnit& u = rest[i];
+            grp.push_back(u);
+            int kcols = 0;
+            for (int sg = 0; sg < u.nseg; ++sg) kcols += S.bcols[u.src_bcol0 + sg].width;
+            fz += 2.0 * kcols * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+          }
+          Edge e = edge(ST_FAR);   // in order behind the marker
+          ev_level = P.nevents++;
+          e.record = ev_level;
+          emit_gemm(lev, grp, fz, true, e);
+          zone_events.push_back({z, ev_level});
+          if (z != 0 || use_zones) zoned = zoned || use_zones;
+        }
       }
     }
     }  // phases
@@ -817,13 +713,25 @@ struct Builder {
 
 }  // namespace
 
+bool latency_bound(const Symbolic& S, int pw) {
+  int maxlevel = -1;
+  for (int s = 0; s < S.nnodes; ++s) maxlevel = std::max(maxlevel, S.level[s]);
+  std::vector<int> widest(maxlevel + 1, 0);
+  for (int s = 0; s < S.nnodes; ++s) widest[S.level[s]] = std::max(widest[S.level[s]], S.ncol(s));
+  double chain_us = 0;
+  for (int w : widest) chain_us += 60.0 * ((w + pw - 1) / pw);
+  const double bulk_us = (double)S.flops / 45e6;   // 45 TFLOP/s
+  return chain_us > 0.25 * bulk_us;
+}
+
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {
   P = Program();
   Builder b(S, opt, P);
   b.run();
 }
 
-void build_solve_program(const Symbolic& S, int pw, SolveProgram& P, const int* node_owner, int rank) {
+void build_solve_program(const Symbolic& S, int pw, int cb, SolveProgram& P, const int* node_owner,
+                         int rank) {
   P = SolveProgram();
   pw = std::min(pw, kPanelMax);
   const int nn = S.nnodes, nbc = S.nbcol();
@@ -839,11 +747,8 @@ void build_solve_program(const Symbolic& S, int pw, SolveProgram& P, const int* 
       u.w = B.width;
       u.nrow = B.nrow;
       u.pw = pw;
-      u.pad_ = 0;
-      for (int c = 0; c < B.width; c += pw) {
-        int pn = std::min(pw, B.width - c);
-        o += (int64_t)pn * pn;
-      }
+      u.cb = cb;
+      o += winv_offset(B.width, pw, cb, (B.width + pw - 1) / pw);
     }
   }
   int maxlevel = -1;

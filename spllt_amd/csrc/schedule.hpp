@@ -4,11 +4,12 @@
 // tile kernel, the elimination tree is cut into levels and every level is a
 // short sequence of *batched* launches whose work lists live in device memory:
 //
-//   per level, per block-column step c, per inner panel p (width <= PW):
-//       POTRF  : diagonal panel blocks      (factorize_block, kernels_mod:1168)
-//       TRSM   : rows below each panel      (solve_block,     kernels_mod:1217)
-//       UPDATE : rest of the block column   (update_block,    kernels_mod:1261)
-//     UPDATE   : trailing block columns of the same node with K = blkn
+//   per level, per block-column step c, per diagonal sub-tile (cb x cb), per panel p (<= PW):
+//       CHAIN  : k_chain_panel, one workgroup per node: POTRF of the panel's diagonal block
+//                (factorize_block, kernels_mod:1168), solve + update inside the sub-tile
+//       SIDE   : rows below the sub-tile, left-looking update and solve in one product
+//                (solve_block + update_block, kernels_mod:1217, :1261)
+//     UPDATE   : rest of the block column / trailing block columns of the same node
 //   UPDATE/scatter: every (node, ancestor block column) pair of the level
 //                (update_between + expand_buffer, kernels_mod:2108, :2010)
 //
@@ -71,96 +72,106 @@ struct PotrfUnit {
   int flags;         // bit 0: block is already a Cholesky factor, only invert it
 };
 
-// All sub-diagonal rows of one block column: X = A * inv(L_tile)^T by blocked
-// substitution over the block column's panels inside ONE kernel (k_trsm_strip).
-struct StripUnit {
+// One step of the panel chain (k_chain_panel), one workgroup: panel [c0, c0+pn) of the
+// diagonal sub-tile [cs, ce) of a block column.  winv_off: where Winv goes in the dinv
+// scratch, a pn x (c0-cs+pn) row-major matrix [ -inv(L_pp) L[c0:c0+pn, cs:c0] | inv(L_pp) ].
+struct ChainUnit {
   int64_t off;       // arena offset of the block column
-  int64_t dinv_off;  // dinv slot of panel 0 (the panels' slots are consecutive)
-  int ld;            // block column width w
-  int row0;          // first stored row of the region (= w: the rows below the diagonal tile)
-  int nrows;         // rows in the region
-  int pw;            // panel width
+  int64_t winv_off;
+  int ld;            // block column width
+  int c0, pn;        // panel: first column, width (<= kPanelMax)
+  int cs, ce;        // sub-tile: columns (= stored rows) [cs, ce)
+  int gcol;          // pivot position of column c0 (error reporting)
 };
+static_assert(sizeof(ChainUnit) == 40, "ChainUnit layout (mirrored in spllt_amd/api.py)");
 
-// One panel step of the chain below its POTRF, fused (k_panel_step): the rows
-// below panel p of a block column are solved against inv(L_pp) and the NEXT
-// 64-wide panel of the node (same block column, or panel 0 of the next block
-// column) receives every update that is still missing: the previous block
-// column (s_*), the source block column's panels before p (global) and panel p
-// itself (straight from LDS).  Row coordinates are stored rows of the source
-// block column.
-struct PanelStepUnit {
-  int64_t off;       // arena offset of the source block column
-  int64_t dinv_off;  // inv(L_pp) in the dinv scratch (row-major, ld = pn)
-  int64_t d_off;     // arena offset of the destination block column (-1: no next panel)
-  int64_t s_off;     // arena offset of the previous block column (-1: none)
-  int ld;            // source block column width
-  int c0, pn;        // panel p: first column, width
-  int nrows;         // rows below the panel's diagonal block
-  int d_ld, d_c0, d_pn;  // destination row width, first column, panel width
-  int d_rshift;      // destination stored row = source stored row - d_rshift
-  int s_ld, s_k;     // previous block column: row width, K extent
-  int s_rshift;      // previous block column stored row = source stored row + s_rshift
-  int pad_;
-};
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5 };
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_STRIP = 3, L_CHAIN = 4, L_PANEL = 5 };
+// streams of the program: the chain (panel chain kernels and the updates that gate them),
+// the side stream (rows below the sub-tiles: off the critical path by one step), the bulk and
+// far streams (trailing / early inter-node updates that run BESIDE a chain: the engine masks
+// them off a few CUs so that chain and side kernels always find a free CU) and the wide stream
+// (launches that have the chip to themselves: no mask)
+enum StreamId : int { ST_CHAIN = 0, ST_BULK = 1, ST_FAR = 2, ST_SIDE = 3, ST_WIDE = 4, ST_COUNT = 5 };
 
 struct Launch {
   int kind;
   int level;
-  int64_t first, count;  // range in potrf_units (L_POTRF) or tiles (L_GEMM)
-  int tile;              // L_GEMM: tile edge (128 or 64 ...)
+  int64_t first, count;  // range in chain_units (L_CHAIN), potrf_units (L_POTRF) or tiles (L_GEMM)
+  int tile;              // L_GEMM: tile edge (128, 64 or 32); L_CHAIN: most rows below a panel
   double flops;          // useful flops of this launch (for reporting)
-  // stream-DAG edges: the launch goes to `stream` (0 = panel stream: POTRF/TRSM
-  // chain, 1 = bulk stream: trailing and inter-node updates) after waiting for
-  // events wait0/wait1 (-1 = none) and records event `record` (-1 = none).
+  // stream-DAG edges: the launch goes to `stream` (StreamId) after waiting for the events
+  // wait[0..3] (-1 = none) and records event `record` (-1 = none).
   int stream = 0;
-  int wait0 = -1, wait1 = -1;
+  int wait[4] = {-1, -1, -1, -1};
   int record = -1;
   int overlap = 0;  // 1: bulk launch that runs beside a panel chain (engine may cap its CU share)
+  void add_wait(int ev) {
+    if (ev < 0) return;
+    for (int& w : wait) {
+      if (w == ev) return;
+      if (w < 0) { w = ev; return; }
+    }
+  }
 };
 
 struct Program {
   int pw = 64;  // inner panel width
-  std::vector<PotrfUnit> potrf_units;
-  std::vector<PanelStepUnit> panel_units;  // L_PANEL (tiles: unit, ti = 32-row tile)
-  std::vector<PotrfUnit> chain_units;  // L_CHAIN: off = block column, n = tile order, flags = panel width
+  int cb = 64;  // chain block: edge of the diagonal sub-tiles the chain kernels walk
+  std::vector<PotrfUnit> potrf_units;  // L_POTRF (operator twins only: inverse of given factors)
+  std::vector<ChainUnit> chain_units;  // L_CHAIN, L_WINV
   std::vector<UpdUnit> units;
   std::vector<UpdTile> tiles;
-  std::vector<StripUnit> strip_units;  // L_STRIP launches: tiles[].unit indexes this, .ti = strip
   std::vector<Launch> launches;
   std::vector<int> relpos;      // per (node, touched ancestor): positions of the node's rows in the ancestor's row list
   int64_t dinv_size = 0;        // doubles
   int nevents = 0;              // number of distinct event ids used by the launches
-  int final_event = -1;         // recorded (on the bulk stream) when everything is done
+  int final_event = -1;         // recorded when everything is done
   double flops_potrf = 0, flops_trsm = 0, flops_update = 0, flops_between = 0;
 };
 
 struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
+  int cb = 64;          // chain block (rounded down to a multiple of pw)
   // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree
   // node, -1 for the (replicated) top tree.  With nranks > 1 the program is
   // [own subtrees] EXCHANGE [top tree].
   int rank = 0;
   int nranks = 1;
   const int* node_owner = nullptr;
-  bool lookahead = true;  // two-stream schedule: panel chain of block column c+1
-                          // overlaps the trailing update by block column c
-  bool lazy_next = false;  // (lookahead, unfused) the update c -> c+1 is merged, panel by panel,
-                          // into the left-looking update launches of block column c+1
-  bool panel_step = false;  // fused TRSM + next-panel update launches (k_panel_step) on levels
-  int panel_step_limit = 768;  // ... whose steps have at most this many 32-row tiles
-  bool slice_between = true;  // (lookahead) inter-node updates are issued in K slices on a third
+  bool lookahead = true;  // multi-stream schedule: the chain of block column c+1 overlaps the
+                          // trailing update by block column c; false: one stream, program order
+  bool slice_between = true;  // (lookahead) inter-node updates are issued in K slices on the far
   int slice_width = 2;        // stream while the panel chains of the level are still running
-  bool fused_strip = false;  // sub-diagonal rows of a block column in one k_trsm_strip launch
-  int strip_limit = 512;    // ... on levels whose steps have at most this many strips
-  bool tile_chain = true;   // with fused_strip: the panel chain of a diagonal tile (w <= 256)
-                            // runs as ONE workgroup (k_tile_chain) instead of 3*np-1 launches
+  bool zones = true;          // (lookahead) the inter-node updates at the end of a level are issued
+                              // sorted by destination block column, one event per zone, so that
+                              // the next level's chains start beside them; the trailing updates
+                              // of a level that starts this way subtract with atomics
+  bool side_on_chain = true;  // the rows below the sub-tiles and the near-zone updates stay on the
+                              // chain stream: more kernels in the chain, no cross-stream hand-offs
+                              // (each costs 10-20 us) inside it
 };
 
+// Winv slot of panel p of a block column of width w (doubles from the block column's slot 0)
+inline int64_t winv_offset(int w, int pw, int cb, int p) {
+  int64_t o = 0;
+  for (int t = 0; t < p; ++t) {
+    const int ct = t * pw, pt = (pw < w - ct) ? pw : w - ct;
+    o += (int64_t)pt * (ct % cb + pt);
+  }
+  return o;
+}
+
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);
+
+// Is the factorization of S bound by the latency of its panel chains rather than by matrix
+// throughput?  Estimate: the longest chain of dependent panel steps through the tree (one step
+// per `pw` columns of the widest node of every level, ~60 us each) against the time the flops
+// take at a typical update rate.  Latency-bound problems get CUs reserved for the chain and the
+// zone pipeline; throughput-bound ones keep the whole chip for the updates (measured: the
+// reservation costs 2-3 % on the 12-48 TFLOP configurations and gains 8 % on the 0.76 TFLOP one).
+bool latency_bound(const Symbolic& S, int pw);
 
 // ---------------------------------------------------------------------------
 // Triangular solves with the device-resident factor (SURVEY.md 8(f) row f2;
@@ -177,7 +188,7 @@ struct SolveUnit {
   int w;             // width
   int nrow;          // rows stored (w diagonal rows + rows below)
   int pw;            // panel width
-  int pad_;
+  int cb;            // chain block (Winv layout, see ChainUnit)
 };
 
 enum SolveKind : int { SV_DIAG_FWD = 0, SV_STRIP_FWD = 1, SV_STRIP_BWD = 2, SV_DIAG_BWD = 3 };
@@ -204,7 +215,7 @@ struct SolveProgram {
 };
 
 // node_owner (per node: owning rank, -1 = top tree) may be null: no partition
-void build_solve_program(const Symbolic& S, int pw, SolveProgram& P, const int* node_owner = nullptr,
-                         int rank = 0);
+void build_solve_program(const Symbolic& S, int pw, int cb, SolveProgram& P,
+                         const int* node_owner = nullptr, int rank = 0);
 
 }  // namespace spx

@@ -46,10 +46,11 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             out[i] = arena[s:s + klen]
         return out
 
-    for kind, level, first, count, tile, _fl, _st, _w0, _w1, _rec in launches:
+    bc_nrow = f.sym("bcol_nrow")
+    for kind, level, first, count, tile in launches[:, :5]:
         if kind == 2:  # EXCHANGE: pack the top-tree block columns, reduce, unpack
             top = f.partition("top_bcols")
-            sl_ = [slice(int(bc_off[b]), int(bc_off[b]) + int(f.sym("bcol_nrow")[b]) * int(bc_w[b]))
+            sl_ = [slice(int(bc_off[b]), int(bc_off[b]) + int(bc_nrow[b]) * int(bc_w[b]))
                    for b in top]
             xbuf = np.concatenate([arena[s_] for s_ in sl_]) if sl_ else np.zeros(0)
             xbuf = exchange(xbuf)
@@ -59,71 +60,40 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 arena[s_] = xbuf[o:o + k]
                 o += k
             continue
-        if kind == 4:  # single-workgroup panel chain = Cholesky of the diagonal tile + panel inverses
+        if kind == 4:  # one step of the panel chain per unit (k_chain_panel)
             for q in f.program("chains")[first:first + count]:
-                w, nt, off, pwq = int(q["ld"]), int(q["n"]), int(q["off"]), int(q["flags"])
-                idx = off + np.arange(nt)[:, None] * w + np.arange(nt)[None, :]
-                blk = np.tril(arena[idx])
-                Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
-                low = np.tril_indices(nt)
-                arena[idx[low]] = Lb[low]
-                slot = int(q["dinv_off"])
-                for c0 in range(0, nt, pwq):
-                    pn = min(pwq, nt - c0)
-                    X = sl.solve_triangular(Lb[c0:c0 + pn, c0:c0 + pn], np.eye(pn), lower=True)
-                    dinv[slot:slot + pn * pn] = X.ravel()
-                    slot += pn * pn
-            continue
-        if kind == 3:  # fused strip TRSM: rows below the diagonal tile, all panels
-            strips = f.program("strips")
-            rs = int(tile)
-            for t in tiles[first:first + count]:
-                q = strips[int(t["unit"])]
-                w, off = int(q["ld"]), int(q["off"])
-                r0 = int(q["row0"]) + int(t["ti"]) * rs
-                nr = min(rs, int(q["row0"]) + int(q["nrows"]) - r0)
-                Lt = np.tril(arena[off:off + w * w].reshape(w, w))
-                rows = arena[off + r0 * w: off + (r0 + nr) * w].reshape(nr, w)
-                arena[off + r0 * w: off + (r0 + nr) * w] = sl.solve_triangular(
-                    Lt, rows.T, lower=True).T.ravel()
-            continue
-        if kind == 5:  # fused panel step: TRSM of the rows below + update of the next panel
-            panels = f.program("panels")
-            tl = tiles[first:first + count]
-            for t in tl:  # pass 1: X = A * inv(L_pp)^T
-                q = panels[int(t["unit"])]
-                ld, off, c0, pn = int(q["ld"]), int(q["off"]), int(q["c0"]), int(q["pn"])
-                D = dinv[int(q["dinv_off"]):int(q["dinv_off"]) + pn * pn].reshape(pn, pn)
-                r0 = c0 + pn + int(t["ti"]) * 32
-                nr = min(32, c0 + pn + int(q["nrows"]) - r0)
-                assert nr > 0
-                idx = off + (r0 + np.arange(nr))[:, None] * ld + c0 + np.arange(pn)[None, :]
-                arena[idx] = arena[idx] @ D.T
-            for t in tl:  # pass 2: next panel -= [S | O | X]_i [S | O | X]_d^T
-                q = panels[int(t["unit"])]
-                if q["d_off"] < 0:
-                    continue
-                ld, off, c0, pn = int(q["ld"]), int(q["off"]), int(q["c0"]), int(q["pn"])
-                rb, dpn = c0 + pn, int(q["d_pn"])
-                i0 = int(t["ti"]) * 32
-                nr = min(32, int(q["nrows"]) - i0)
+                ld, off = int(q["ld"]), int(q["off"])
+                c0, pn, cs, ce = int(q["c0"]), int(q["pn"]), int(q["cs"]), int(q["ce"])
+                cq = c0 - cs
 
-                def rows_of(r_first, cnt):
-                    parts = []
-                    if q["s_off"] >= 0:
-                        sld, sk, rsh = int(q["s_ld"]), int(q["s_k"]), int(q["s_rshift"])
-                        ii = int(q["s_off"]) + (r_first + rsh + np.arange(cnt))[:, None] * sld + np.arange(sk)[None, :]
-                        parts.append(arena[ii])
-                    ii = off + (r_first + np.arange(cnt))[:, None] * ld + np.arange(c0 + pn)[None, :]
-                    parts.append(arena[ii])
-                    return np.hstack(parts)
-                P = rows_of(rb + i0, nr) @ rows_of(rb, dpn).T
-                ii = np.arange(nr)[:, None] + i0
-                jj = np.arange(dpn)[None, :]
-                keep = ii >= jj
-                idx = (int(q["d_off"]) + (rb + ii - int(q["d_rshift"])) * int(q["d_ld"]) +
-                       int(q["d_c0"]) + jj)
-                arena[idx[keep]] -= P[keep]
+                def idx(r0, r1, k0, k1):
+                    return off + np.arange(r0, r1)[:, None] * ld + np.arange(k0, k1)[None, :]
+                dd = idx(c0, c0 + pn, c0, c0 + pn)
+                blk = np.tril(arena[dd])
+                Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
+                low = np.tril_indices(pn)
+                arena[dd[low]] = Lb[low]
+                inv = sl.solve_triangular(Lb, np.eye(pn), lower=True)
+                wo = int(q["winv_off"])
+                Wv = dinv[wo:wo + pn * (cq + pn)].reshape(pn, cq + pn)   # view: only the inverse part
+                Wv[:, cq:] = inv
+                if ce > c0 + pn:
+                    xi = idx(c0 + pn, ce, c0, c0 + pn)
+                    X = arena[xi] @ inv.T
+                    arena[xi] = X
+                    ti = idx(c0 + pn, ce, c0 + pn, ce)
+                    keep = np.tril(np.ones((ce - c0 - pn,) * 2, dtype=bool))
+                    arena[ti[keep]] -= (X @ X.T)[keep]
+            continue
+        if kind == 5:  # W part of Winv (k_winv): -inv(L_pp) L[c0:c0+pn, cs:c0]
+            for q in f.program("chains")[first:first + count]:
+                ld, off = int(q["ld"]), int(q["off"])
+                c0, pn, cs = int(q["c0"]), int(q["pn"]), int(q["cs"])
+                cq = c0 - cs
+                wo = int(q["winv_off"])
+                Wv = dinv[wo:wo + pn * (cq + pn)].reshape(pn, cq + pn)
+                rows = off + np.arange(c0, c0 + pn)[:, None] * ld + np.arange(cs, c0)[None, :]
+                Wv[:, :cq] = -Wv[:, cq:] @ arena[rows]
             continue
         if kind == 0:
             for q in potrf[first:first + count]:
@@ -147,9 +117,11 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             for sg in range(int(u["nseg"])):
                 Ablk = seg_rows(u, sg, int(u["src_r0"]) + i0, mi, False)
                 if u["mode"] == MODE_TRSM:
-                    n = int(u["dinv_ld"])
-                    X = dinv[int(u["dinv_off"]):int(u["dinv_off"]) + n * n].reshape(n, n)
-                    Bblk = X[j0:j0 + nj, :Ablk.shape[1]]
+                    # B = the unit's N x dinv_ld matrix in the dinv scratch (Winv of a panel)
+                    n, ldw = int(u["N"]), int(u["dinv_ld"])
+                    X = dinv[int(u["dinv_off"]):int(u["dinv_off"]) + n * ldw].reshape(n, ldw)
+                    assert Ablk.shape[1] == ldw
+                    Bblk = X[j0:j0 + nj, :]
                 else:
                     Bblk = seg_rows(u, sg, int(u["src_c0"]) + j0, nj, True)
                 P += Ablk @ Bblk.T

@@ -45,7 +45,7 @@ EDGE_GPU = EDGE + [("dense1100-nb1024", lambda: sp.csc_matrix(np.ones((1100, 110
 
 
 @pytest.mark.parametrize("name,gen,kw", EDGE, ids=[e[0] for e in EDGE])
-@pytest.mark.parametrize("flags", [0, 2, 32])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_edge_case_program_reproduces_dense_cholesky(name, gen, kw, flags):
     A = gen()
     f, val = make_case(A, engine_flags=flags, **kw)

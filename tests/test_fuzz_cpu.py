@@ -34,44 +34,24 @@ def _matrix(rng, seed):
 
 
 def _dag_is_ordered(f):
-    launches, acc = ts._access_sets(f)
-    n = len(launches)
-    rec_at, last, before = {}, {}, [0] * n
-    for i, (kind, level, first, count, tile, _fl, st, w0, w1, rec) in enumerate(launches):
-        m = 0
-        if st in last:
-            j = last[st]
-            m |= before[j] | (1 << j)
-        for w in (w0, w1):
-            if w >= 0:
-                j = rec_at[w]
-                m |= before[j] | (1 << j)
-        before[i] = m
-        last[st] = i
-        if rec >= 0:
-            rec_at[int(rec)] = i
-    for j in range(n):
-        Rj, Wj, Aj = acc[j]
-        for i in range(j):
-            Ri, Wi, Ai = acc[i]
-            if (Wi & (Rj | Wj | Aj)) or (Wj & (Ri | Ai)) or (Ai & Rj) or (Aj & Ri):
-                if not (before[j] >> i & 1):
-                    return False
-    return True
+    return not ts.dag_violations(f)[0]
 
 
 @pytest.mark.parametrize("seed", range(30))
-def test_fuzz_program_single_gpu(seed):
+def test_fuzz_program_single_gpu(seed, monkeypatch):
     rng = np.random.default_rng(3000 + seed)
     A = _matrix(rng, seed)
     nb = int(rng.choice([5, 8, 16, 24, 33, 48, 100]))
     pw = int(rng.choice([4, 5, 8, 12, 16, 24, 64]))
     nemin = int(rng.choice([1, 4, 16, 32]))
-    flags = int(rng.choice([0, 0, 2, 4, 6, 12, 16, 32, 34, 64, 66]))
+    flags = int(rng.choice([0, 0, 2, 64, 66, 512, 576, 1024, 2048, 2560]))
+    cb = int(rng.choice([0, 0, 16, 24, 40, 64]))
+    if cb:
+        monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
     f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
     got = emulate_program(f, val)
-    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-12, (nb, pw, nemin, flags)
-    assert _dag_is_ordered(f), (nb, pw, nemin, flags)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-12, (nb, pw, nemin, flags, cb)
+    assert _dag_is_ordered(f), (nb, pw, nemin, flags, cb)
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -37,13 +37,14 @@ def test_fuzz_factor_and_solve(seed):
     nb = int(rng.choice([5, 7, 16, 24, 33, 48, 64, 100, 130, 200]))
     pw = int(rng.choice([4, 5, 8, 10, 12, 16, 24, 32, 40, 48, 64]))
     nemin = int(rng.choice([1, 4, 16, 32, 64]))
-    flags = int(rng.choice([0, 0, 0, 2, 4, 12, 16, 32, 64]))
-    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
+    flags = int(rng.choice([0, 0, 0, 2, 64, 66, 256, 512, 576, 1024, 2048]))
+    cb = int(rng.choice([0, 0, 32, 48, 96, 128, 256]))
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags, chain_block=cb or None)
     got = f.factor(val).wait().get_factor()
     o, rc = oracle_factor(f, val)
     assert rc == 0
     mask = lower_mask(f)
-    assert rel_err(got, o.arena(), mask) <= 1e-12, (nb, pw, nemin, flags)
+    assert rel_err(got, o.arena(), mask) <= 1e-12, (nb, pw, nemin, flags, cb)
     assert np.all(got[~mask] == 0.0)
     nrhs = int(rng.integers(1, 6))
     X = rng.standard_normal((f.n, nrhs))
@@ -53,14 +54,14 @@ def test_fuzz_factor_and_solve(seed):
         assert bwd_err(A, Y[:, q], B[:, q]) <= 1e-14, (nb, pw, nemin, flags)
 
 
-@pytest.mark.parametrize("flags", [0, 4, 12, 16, 32, 64])
+@pytest.mark.parametrize("flags", [0, 2, 64, 512])
+@pytest.mark.parametrize("cb", [None, 40, 256])
 @pytest.mark.parametrize("nb,pw", [(48, 5), (48, 24), (100, 10), (100, 40), (130, 48), (33, 12)])
-def test_ragged_panels_in_every_engine_variant(flags, nb, pw):
+def test_ragged_panels_in_every_engine_variant(flags, cb, nb, pw):
     """panel widths that are no multiple of 16 (or 4) and do not divide nb, in
-    every engine variant (the fused strip kernel once zeroed the columns of the
-    next panel when a panel ended inside a 16-column MFMA tile)"""
+    every engine variant and with sub-tiles that end inside a block column"""
     A = matgen.fe27((5, 4, 4), 3)
-    f, val = make_case(A, nb=nb, nemin=4, panel_width=pw, engine_flags=flags)
+    f, val = make_case(A, nb=nb, nemin=4, panel_width=pw, engine_flags=flags, chain_block=cb)
     got = f.factor(val).wait().get_factor()
     o, rc = oracle_factor(f, val)
     assert rc == 0
@@ -104,11 +105,13 @@ def _partitioned_factor_and_solve(A, world, nb, nemin, pw):
         Y[:, pos] = B.T
         ys.append(torch.tensor(Y, device="cuda") * m)
         masks.append(m)
+    torch.cuda.synchronize()
     for f, y in zip(fs, ys):
         f.solve_dev(y.data_ptr(), 2, 0, 0)
     total = torch.stack(ys).sum(dim=0)
     for y in ys:
         y.copy_(total)
+    torch.cuda.synchronize()   # torch's stream is not the engines' stream
     for f, y, m in zip(fs, ys, masks):
         f.solve_dev(y.data_ptr(), 2, 0, 1)
         f.solve_dev(y.data_ptr(), 2, 0, 2)

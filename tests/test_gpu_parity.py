@@ -424,19 +424,42 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("flags", [2, 4, 12, 16, 32, 34])
-def test_engine_variants_match_oracle(flags):
-    """single-stream program (2), fused strip-TRSM + tile lookahead with the
-    single-workgroup tile chain (4) and with per-panel launches (12), lazy
-    next-column update (16), separate TRSM / update launches instead of the
-    fused panel steps (32, 34)."""
+@pytest.mark.parametrize("flags", [2, 64, 66, 256, 512, 576, 1024, 2048])
+@pytest.mark.parametrize("cb", [None, 32, 96, 160])
+def test_engine_variants_match_oracle(flags, cb):
+    """single-stream program (2), inter-node updates only at the end of a level (64), both
+    (66), no CU reservation (256), rows below the sub-tiles on a side stream (512); chain
+    block = one panel (default), several panels per diagonal sub-tile, whole block columns."""
     A = matgen.nd_like((12, 11, 10), 2)
-    f, val = make_case(A, nb=64, nemin=16, panel_width=32, engine_flags=flags)
-    assert ((f.program("launches")[:, 0] == 5).any()) == (flags in (32, 34))
+    f, val = make_case(A, nb=160, nemin=16, panel_width=32, engine_flags=flags, chain_block=cb)
+    assert f.program("chain_block") == (cb or 64) // 32 * 32
     got = f.factor(val).wait().get_factor()
     o, rc = oracle_factor(f, val)
     assert rc == 0
     assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
+
+
+@pytest.mark.parametrize("flags", [128, 130, 192, 640])
+@pytest.mark.parametrize("nb,pw,cb", [(48, 5, None), (100, 40, 100), (130, 48, 96), (33, 12, 24),
+                                      (256, 64, 256), (200, 24, 72)])
+def test_no_kernel_reads_uninitialised_lds(flags, nb, pw, cb):
+    """Engine flag 128: before EVERY kernel launch of the factorization a poison kernel
+    fills the whole LDS of every CU with signalling-NaN bit patterns.  A kernel that reads
+    LDS it has not written (zero padding assumed, columns past a ragged panel, ...) then
+    produces NaNs deterministically instead of depending on what the previous kernel left
+    there.  Ragged shapes: panel widths that are no multiple of 16 or 4 and do not divide
+    the tile size, tile sizes that divide nothing.  Run once."""
+    A = matgen.fe27((5, 4, 4), 3) if nb < 200 else matgen.nd_like((10, 9, 9), 3)
+    f, val = make_case(A, nb=nb, nemin=4, panel_width=pw, engine_flags=flags, chain_block=cb)
+    got = f.factor(val).wait().get_factor()
+    assert np.isfinite(got).all()
+    o, rc = oracle_factor(f, val)
+    assert rc == 0
+    assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
 @pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson2d(40), 16), (lambda: matgen.nd_like((11, 10, 9), 2), 64),

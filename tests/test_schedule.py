@@ -117,171 +117,201 @@ def sparent_of(f, a, _cache={}):
 
 
 def _access_sets(f):
-    """Per launch: (reads, writes, atomics) as sets of resources.  A block
-    column b is two resources: 2b = its diagonal-tile rows (stored rows <
-    width), 2b+1 = the rows below; 2*nbcol + b = the dinv slots of b.  This is
-    the granularity at which the stream DAG must order conflicting launches."""
+    """Per launch: (reads, writes, atomics), each a list of resources.  A resource is a
+    rectangle (block column, stored rows [r0, r1), columns [c0, c1)) of the arena or a Winv
+    slot ("w", block column, panel).  This is the granularity at which the stream DAG must
+    order conflicting launches: chain steps, side launches and the updates of one block
+    column work on disjoint rectangles of it at the same time."""
     launches = f.program("launches")
-    potrf, units, tiles = f.program("potrf"), f.program("units"), f.program("tiles")
-    strips = f.program("strips")
-    off, bw = f.sym("bcol_off"), f.sym("bcol_width")
-    nbc = len(off)
+    units, tiles, chains = f.program("units"), f.program("tiles"), f.program("chains")
+    off, bw, bnr = f.sym("bcol_off"), f.sym("bcol_width"), f.sym("bcol_nrow")
+    pw = int(chains["pn"].max()) if len(chains) else 64
 
-    def parts(b, r0, cnt):
-        out = set()
-        if cnt <= 0:
-            return out
-        if r0 < bw[b]:
-            out.add(2 * b)
-        if r0 + cnt > bw[b]:
-            out.add(2 * b + 1)
-        return out
+    def bcol_of(o):
+        return int(np.searchsorted(off, o, side="right") - 1)
 
     out = []
-    for kind, level, first, count, tile, _fl, st, w0, w1, rec in launches:
-        R, W, At = set(), set(), set()
-        if kind == 0:
-            for q in potrf[first:first + count]:
-                b = int(np.searchsorted(off, q["off"], side="right") - 1)
-                W.add(2 * b)
-                R.add(2 * b)
-                W.add(2 * nbc + b)
-        elif kind == 4:
-            for q in f.program("chains")[first:first + count]:
-                b = int(np.searchsorted(off, q["off"], side="right") - 1)
-                W |= {2 * b, 2 * nbc + b}
-                R.add(2 * b)
-        elif kind == 3:
-            for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
-                q = strips[uid]
-                b = int(np.searchsorted(off, q["off"], side="right") - 1)
-                R |= {2 * b, 2 * nbc + b}
-                W.add(2 * b + 1)
+    for kind, level, first, count, tile in launches[:, :5]:
+        R, W, At = [], [], []
+        if kind == 4:
+            for q in chains[first:first + count]:
+                b = bcol_of(q["off"])
+                c0, pn, cs, ce = int(q["c0"]), int(q["pn"]), int(q["cs"]), int(q["ce"])
+                R.append((b, c0, c0 + pn, cs, c0))
+                R.append((b, c0, ce, c0, ce))
+                W.append((b, c0, ce, c0, ce))
+                W.append(("wi", b, c0 // pw))      # inverse part of Winv
+        elif kind == 5:
+            for q in chains[first:first + count]:
+                b = bcol_of(q["off"])
+                c0, pn, cs = int(q["c0"]), int(q["pn"]), int(q["cs"])
+                R.append((b, c0, c0 + pn, cs, c0))
+                R.append(("wi", b, c0 // pw))
+                W.append(("ww", b, c0 // pw))      # W part of Winv
         elif kind == 1:
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 u = units[uid]
-                db = int(np.searchsorted(off, u["d_off"], side="right") - 1)
+                db = bcol_of(u["d_off"])
+                M, N = int(u["M"]), int(u["N"])
                 for sg in range(int(u["nseg"])):
                     sb = int(u["src_bcol0"]) + sg
                     sh = int(u["seg_r0"]) + sg * int(u["seg_stride"])
-                    R |= parts(sb, int(u["src_r0"]) - sh, int(u["M"]))
+                    k0 = int(u["k0"]) if u["nseg"] == 1 else 0
+                    k1 = k0 + int(u["klen"]) if (u["nseg"] == 1 and u["klen"] >= 0) else int(bw[sb])
+                    ra = int(u["src_r0"]) - sh
+                    R.append((sb, ra, ra + M, k0, k1))
                     if u["mode"] != 2:
-                        R |= parts(sb, int(u["src_c0"]) - sh, int(u["N"]))
+                        rb = int(u["src_c0"]) - sh
+                        R.append((sb, rb, rb + N, k0, k1))
+                dr0, dc0 = int(u["d_row0"]), int(u["d_col0"])
                 if u["mode"] == 2:
-                    R.add(2 * nbc + db)
-                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
+                    R.append(("wi", db, dc0 // pw))
+                    if int(u["klen"]) > N:
+                        R.append(("ww", db, dc0 // pw))
+                    W.append((db, dr0, dr0 + M, dc0, dc0 + N))
                 elif u["mode"] == 1:
-                    At |= {2 * db, 2 * db + 1}
+                    At.append((db, 0, int(bnr[db]), 0, int(bw[db])))
                 elif u["atomic"]:
-                    At |= parts(db, int(u["d_row0"]), int(u["M"]))
+                    At.append((db, dr0, dr0 + M, dc0, dc0 + N))
                 else:
                     # plain read-modify-write: the launch must own the destination
-                    W |= parts(db, int(u["d_row0"]), int(u["M"]))
-        elif kind == 5:
-            panels = f.program("panels")
-            for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
-                q = panels[uid]
-                b = int(np.searchsorted(off, q["off"], side="right") - 1)
-                rb, nr = int(q["c0"]) + int(q["pn"]), int(q["nrows"])
-                R |= parts(b, rb, nr) | {2 * b, 2 * nbc + b}
-                W |= parts(b, rb, nr)
-                if q["s_off"] >= 0:
-                    sb = int(np.searchsorted(off, q["s_off"], side="right") - 1)
-                    R |= parts(sb, rb + int(q["s_rshift"]), nr)
-                if q["d_off"] >= 0:
-                    db = int(np.searchsorted(off, q["d_off"], side="right") - 1)
-                    At |= parts(db, rb - int(q["d_rshift"]), nr)
+                    W.append((db, dr0, dr0 + M, dc0, dc0 + N))
         out.append((R, W, At))
     return launches, out
+
+
+def _overlap(a, b):
+    if isinstance(a[0], str) or isinstance(b[0], str):
+        return a == b
+    return (a[0] == b[0] and a[1] < b[2] and b[1] < a[2] and a[3] < b[4] and b[3] < a[4] and
+            a[1] < a[2] and a[3] < a[4] and b[1] < b[2] and b[3] < b[4])
+
+
+def _any_overlap(xs, ys):
+    if not xs or not ys:
+        return False
+    by = {}
+    for y in ys:
+        by.setdefault(y[1] if isinstance(y[0], str) else y[0], []).append(y)
+    return any(_overlap(x, y) for x in xs for y in by.get(x[1] if isinstance(x[0], str) else x[0], ()))
+
+
+def dag_violations(f):
+    """Pairs of launches that conflict (write/write, read/write, atomic/plain) without being
+    ordered by stream order or an event edge, plus checks of the event bookkeeping."""
+    launches, acc = _access_sets(f)
+    n = len(launches)
+    rec_at, last_in_stream = {}, {}
+    before = [0] * n  # bitset of launches that happen-before launch i
+    for i, l in enumerate(launches):
+        st, rec, waits = int(l[6]), int(l[7]), l[8:12]
+        m = 0
+        if st in last_in_stream:
+            j = last_in_stream[st]
+            m |= before[j] | (1 << j)
+        for w in waits:
+            if w >= 0:
+                j = rec_at[int(w)]          # a wait must refer to an earlier record
+                m |= before[j] | (1 << j)
+        before[i] = m
+        last_in_stream[st] = i
+        if rec >= 0:
+            assert rec not in rec_at, "every event is recorded once"
+            rec_at[rec] = i
+    bad = []
+    for j in range(n):
+        Rj, Wj, Aj = acc[j]
+        for i in range(j):
+            if before[j] >> i & 1:
+                continue
+            Ri, Wi, Ai = acc[i]
+            if (_any_overlap(Wi, Rj) or _any_overlap(Wi, Wj) or _any_overlap(Wi, Aj) or
+                    _any_overlap(Wj, Ri) or _any_overlap(Wj, Ai) or _any_overlap(Ai, Rj) or
+                    _any_overlap(Aj, Ri)):
+                bad.append((i, j, launches[i].tolist(), launches[j].tolist()))
+    return bad, launches, before, rec_at, last_in_stream
 
 
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
                                         (lambda: matgen.poisson3d(9), 24, 8),
-                                        (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8)])  # many block columns per node
-@pytest.mark.parametrize("flags", [0, 4, 12, 16, 32])
-def test_stream_dag_orders_every_conflict(gen, nb, pw, flags):
-    """Two-stream lookahead program: any two launches that touch the same block
-    column (write/write, read/write, atomic/plain) must be ordered by stream
-    order or an event edge; concurrent atomics into one destination are fine."""
+                                        (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8),   # many block columns per node
+                                        (lambda: matgen.nd_like((9, 8, 8), 2), 100, 8)])
+@pytest.mark.parametrize("cb", [0, 16, 40])
+@pytest.mark.parametrize("flags", [0, 64, 512, 576, 1024, 2048, 2560])
+def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
+    """Multi-stream program (chain, side, bulk, far, wide): any two launches that touch the
+    same entries (write/write, read/write, atomic/plain) must be ordered by stream order or
+    an event edge; concurrent atomics into one destination are fine.  cb: chain block smaller
+    than the block column, so that block columns are walked in several sub-tiles."""
+    if cb:
+        monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
     A = gen()
     f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
-    launches, acc = _access_sets(f)
-    n = len(launches)
+    bad, launches, before, rec_at, last_in_stream = dag_violations(f)
+    assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
-    assert ((launches[:, 0] == 3).any()) == (flags in (4, 12)), "fused strip launches only with flag 4"
-    assert ((launches[:, 0] == 4).any()) == (flags == 4 and pw % 16 == 0), \
-        "tile-chain launches with flag 4 (bit 3 disables; panel widths that are no multiple of 16 too)"
-    assert ((launches[:, 0] == 5).any()) == (flags == 32), "fused panel steps with bit 5 (not in strip mode)"
-    rec_at = {}
-    last_in_stream = {}
-    before = [0] * n  # bitset of launches that happen-before launch i
-    for i, (kind, level, first, count, tile, _fl, st, w0, w1, rec) in enumerate(launches):
-        m = 0
-        if st in last_in_stream:
-            j = last_in_stream[st]
-            m |= before[j] | (1 << j)
-        for w in (w0, w1):
-            if w >= 0:
-                j = rec_at[w]          # a wait must refer to an earlier record
-                m |= before[j] | (1 << j)
-        before[i] = m
-        last_in_stream[st] = i
-        if rec >= 0:
-            rec_at[int(rec)] = i
-    for j in range(n):
-        Rj, Wj, Aj = acc[j]
-        for i in range(j):
-            Ri, Wi, Ai = acc[i]
-            conflict = (Wi & (Rj | Wj | Aj)) or (Wj & (Ri | Ai)) or (Ai & Rj) or (Aj & Ri)
-            if conflict:
-                assert before[j] >> i & 1, (i, j, launches[i].tolist(), launches[j].tolist())
+    assert ((launches[:, 6] == 3).any()) == bool(flags & 512), "side-stream launches only in that variant"
+    assert (launches[:, 0] == 4).any()
     # the final event covers everything: last launch of each stream precedes it
     fin = max(rec_at.values())
     for st, i in last_in_stream.items():
         assert i == fin or (before[fin] >> i & 1) or st == launches[fin, 6]
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
 def test_single_stream_program_has_no_events():
     A = matgen.poisson2d(20)
     f, val = make_case(A, nb=8, nemin=4, engine_flags=2)
     L = f.program("launches")
-    assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all()
+    assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all()   # one stream, no record, no waits
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
-@pytest.mark.parametrize("flags", [0, 4, 2, 6, 12, 16, 32, 34])
-def test_program_variants_agree(flags):
-    """fused strip / per-panel TRSM, two-stream / single-stream programs all
-    reproduce the same factor (interpreted in numpy)."""
+@pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048])
+@pytest.mark.parametrize("cb", [0, 16, 32])
+def test_program_variants_agree(flags, cb, monkeypatch):
+    """multi-stream / single-stream programs, with and without early inter-node slices, rows
+    below the sub-tiles on the chain stream or on a side stream (512), one or several panels
+    per diagonal sub-tile: all reproduce the same factor (interpreted in numpy)."""
+    if cb:
+        monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
-    L = f.program("launches")
-    assert ((L[:, 0] == 3).any()) == (flags in (4, 12))   # strip kernel needs the two-stream program
-    # fused panel steps with bit 5 unless the strip mode (bit 2, two-stream only) is active
-    assert ((L[:, 0] == 5).any()) == (bool(flags & 32) and not ((flags & 4) and not (flags & 2)))
+    assert f.program("chain_block") == (cb or 64) // 16 * 16
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
 @pytest.mark.parametrize("flags", [0, 64])
 def test_inter_node_updates_are_sliced_over_the_far_stream(flags):
-    """Default program: the inter-node update of a node is issued in K slices on
-    stream 2 while the level's panel chains still run (nodes that finish early
-    go completely); engine flag 64 keeps one launch per level.  Both reproduce
-    the oracle's factor when interpreted in numpy."""
+    """The inter-node updates run on the far stream.  At the end of a level they are issued
+    sorted by destination zone, one launch + event per zone (block column c of the nodes of
+    the next level), so that step c of the next level only waits for zone c.  Default program:
+    part of a node's update is issued even earlier, in K slices, while the level's panel
+    chains still run (nodes that finish early go completely); engine flag 64 turns the slices
+    off.  Both reproduce the oracle's factor when interpreted in numpy."""
     A = matgen.nd_like((9, 8, 8), 2)
     f, val = make_case(A, nb=8, nemin=8, panel_width=8, engine_flags=flags)
     L = f.program("launches")
-    far = L[L[:, 6] == 2]
-    if flags == 0:
-        assert len(far) >= 4
-        units, tiles = f.program("units"), f.program("tiles")
-        nseg = [int(units[int(tiles[int(l[2])]["unit"])]["nseg"]) for l in far if l[3] > 0]
-        assert min(nseg) >= 1 and max(nseg) >= 2          # K slices of several block columns
-        assert all(units[int(tiles[int(l[2])]["unit"])]["mode"] == 1 for l in far if l[3] > 0)
-    else:
-        assert len(far) == 0
+    far = L[(L[:, 6] == 2) & (L[:, 3] > 0)]
+    units, tiles = f.program("units"), f.program("tiles")
+    node_bc0, bc_node = f.sym("node_bcol0"), f.sym("bcol_node")
+    assert len(far) >= 4
+    partial = 0
+    for l in far:
+        for uid in sorted(set(tiles[int(l[2]):int(l[2]) + int(l[3])]["unit"].tolist())):
+            u = units[uid]
+            assert u["mode"] == 1
+            s = int(bc_node[int(u["src_bcol0"])])
+            if int(u["nseg"]) < int(node_bc0[s + 1] - node_bc0[s]):
+                partial += 1
+    assert (partial > 0) == (flags == 0)     # K slices only in the default program
+    # one event per zone launch, and the chain steps of later levels wait for far-stream events
+    far_events = set(int(e) for e in L[L[:, 6] == 2][:, 7] if e >= 0)
+    chain_waits = set(int(w) for w in L[L[:, 0] == 4][:, 8:12].ravel() if w >= 0)
+    assert len(far_events & chain_waits) >= 3
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
