@@ -84,6 +84,21 @@ void spllt_hip_analyse_ordered(void **akeep, void **fkeep, spllt_options_t *opti
                                const int *ptr, const int *row, spllt_inform_t *info, int *order,
                                const int *order_in);
 
+/* analyse from a complete symbolic factorization: the quintuple SpLLT's own spllt_analyse
+ * takes from SSIDS (akeep%sptr, %sparent, %rptr, %rlist and the pivot order, reference
+ * src/spllt_analyse_mod.F90:129-158), all 1-based exactly as SSIDS delivers them: sptr
+ * (nnodes+1), sparent (nnodes, virtual root = nnodes+1), rptr (nnodes+1, 64-bit), rlist
+ * (pivot positions, sorted per node, the node's own columns first), order_in[i] = position
+ * of variable i.  The factorization then uses exactly SSIDS' supernode partition and
+ * assembly tree (no ordering, supernode detection or amalgamation of our own), so a
+ * reference build that keeps SPRAL/Metis for the analyse gets the same tree on both paths.
+ * Invalid input (not a permutation, nodes not postordered, unsorted row lists, pattern of A
+ * not covered) -> info->flag = SPLLT_ERROR_PARAMETER. */
+void spllt_hip_analyse_symbolic(void **akeep, void **fkeep, spllt_options_t *options, int n,
+                                const int *ptr, const int *row, spllt_inform_t *info, int nnodes,
+                                const int *sptr, const int *sparent, const int64_t *rptr,
+                                const int *rlist, const int *order_in);
+
 int spllt_hip_sym_info(const void *akeep, spllt_hip_sym_info_t *out);
 /* copy a named 0-based array of the symbolic structure; returns its length in
  * elements (call with buf = NULL to query).  int32 arrays: "order", "sptr",
@@ -119,7 +134,9 @@ int spllt_hip_set_chain_block(void *fkeep, int chain_block);
  * Call after spllt_analyse (options.prune_tree = 1, options.ncpu = nranks) and
  * before the first spllt_factor.  Every rank factorizes the pruned subtrees it
  * owns; spllt_factor then stops at the exchange point with the top-tree block
- * columns packed into the caller's device buffer (exchange_elems doubles).
+ * columns packed into the caller's device buffer (exchange_elems doubles; the last one
+ * carries the "not positive definite" indicator, so that after the sum every rank
+ * reports the same outcome).
  * The caller sums that buffer over all ranks (RCCL all-reduce over xGMI: this
  * is the extend-add that replaces spllt_scatter_block on generated elements,
  * reference src/spllt_factorization_mod.F90:39-191), calls spllt_hip_continue,
@@ -139,6 +156,13 @@ int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange
  * spllt_solve itself returns SPLLT_ERROR_UNIMPLEMENTED on a partitioned factor. */
 int spllt_hip_solve_dev(void *fkeep, void *y_dev, int nrhs, int job, int phase);
 int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
+/* The HIP stream (hipStream_t) every caller-visible operation of this handle is ordered on:
+ * spllt_factor ends by packing the exchange buffer on it and spllt_hip_continue starts by
+ * unpacking it there.  A caller that enqueues its collective ON this stream (RCCL takes a
+ * stream argument; torch: torch.cuda.ExternalStream) needs no host synchronisation between
+ * the phases of a partitioned factorization.  Creates the device engine if necessary;
+ * NULL without a HIP device. */
+void *spllt_hip_engine_stream(void *fkeep);
 int spllt_hip_continue(void *fkeep);
 /* "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),
  * "map_keep" (uint8 per val->L map entry: scattered on this rank) */

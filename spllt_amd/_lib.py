@@ -54,7 +54,7 @@ HIP_SYMBOLS = [
     "spllt_hip_get_factor", "spllt_hip_device_factor", "spllt_hip_factor_times",
     "spllt_hip_program_get", "spllt_hip_profile", "spllt_hip_last_error", "spllt_hip_version",
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
-    "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block",
+    "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic",
 ]
 
 _lib = None
@@ -77,6 +77,9 @@ def load():
     lib.spllt_analyse.restype = None
     lib.spllt_hip_analyse_ordered.argtypes = [vpp, vpp, opt, C.c_int, ip, ip, inf, ip, ip]
     lib.spllt_hip_analyse_ordered.restype = None
+    lib.spllt_hip_analyse_symbolic.argtypes = [vpp, vpp, opt, C.c_int, ip, ip, inf, C.c_int, ip, ip,
+                                               C.POINTER(C.c_int64), ip, ip]
+    lib.spllt_hip_analyse_symbolic.restype = None
     lib.spllt_factor.argtypes = [vp, vp, opt, C.c_int, dp, inf]
     lib.spllt_factor.restype = None
     lib.spllt_hip_factor_dev.argtypes = [vp, vp, opt, C.c_int, vp, inf]
@@ -112,6 +115,8 @@ def load():
     lib.spllt_hip_sym_get.restype = C.c_int64
     lib.spllt_hip_set_engine.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.spllt_hip_set_engine.restype = C.c_int
+    lib.spllt_hip_engine_stream.argtypes = [vp]
+    lib.spllt_hip_engine_stream.restype = vp
     lib.spllt_hip_set_chain_block.argtypes = [vp, C.c_int]
     lib.spllt_hip_set_chain_block.restype = C.c_int
     lib.spllt_hip_wait.argtypes = [vp]

@@ -66,7 +66,10 @@ class Factorization:
     """One analysed pattern: owns the akeep/fkeep handle pair."""
 
     def __init__(self, n, ptr, row, nb=256, nemin=32, prune_tree=True, ncpu=1, order=None,
-                 panel_width=None, tile=None, engine_flags=0, chain_block=None):
+                 panel_width=None, tile=None, engine_flags=0, chain_block=None, symbolic=None):
+        """symbolic: optional dict with the SSIDS-style quintuple (0-based numpy arrays
+        "sptr", "sparent", "rptr", "rlist", "order"): the analyse then takes exactly this
+        supernode partition and tree (spllt_hip_analyse_symbolic)."""
         self.lib = _lib.load()
         self.n = int(n)
         self.ptr = np.ascontiguousarray(ptr, dtype=np.int32)
@@ -81,7 +84,19 @@ class Factorization:
         self.fkeep = C.c_void_p(None)
         self.info = spllt_inform_t()
         self.order = np.zeros(max(n, 1), dtype=np.int32)
-        if order is None:
+        if symbolic is not None:
+            sy = symbolic
+            sp = np.ascontiguousarray(np.asarray(sy["sptr"]) + 1, dtype=np.int32)
+            spar = np.ascontiguousarray(np.asarray(sy["sparent"]) + 1, dtype=np.int32)
+            rp = np.ascontiguousarray(np.asarray(sy["rptr"]) + 1, dtype=np.int64)
+            rl = np.ascontiguousarray(np.asarray(sy["rlist"]) + 1, dtype=np.int32)
+            oin = np.ascontiguousarray(np.asarray(sy["order"]) + 1, dtype=np.int32)
+            self.lib.spllt_hip_analyse_symbolic(C.byref(self.akeep), C.byref(self.fkeep),
+                                                C.byref(self.options), n, _ip(self.ptr), _ip(self.row),
+                                                C.byref(self.info), len(spar), _ip(sp), _ip(spar),
+                                                rp.ctypes.data_as(C.POINTER(C.c_int64)), _ip(rl), _ip(oin))
+            self.order[:n] = oin[:n]
+        elif order is None:
             self.lib.spllt_analyse(C.byref(self.akeep), C.byref(self.fkeep), C.byref(self.options),
                                    n, _ip(self.ptr), _ip(self.row), C.byref(self.info),
                                    _ip(self.order))
@@ -234,6 +249,13 @@ class Factorization:
         rc = self.lib.spllt_hip_set_exchange_buffer(self.fkeep, C.c_void_p(dev_ptr))
         if rc < 0:
             raise SplltError("spllt_hip_set_exchange_buffer", rc)
+
+    def engine_stream(self):
+        """hipStream_t (integer) on which the exchange buffer is packed / unpacked"""
+        p = self.lib.spllt_hip_engine_stream(self.fkeep)
+        if not p:
+            raise SplltError("spllt_hip_engine_stream", -30, self.last_error())
+        return int(p)
 
     def continue_after_exchange(self):
         rc = self.lib.spllt_hip_continue(self.fkeep)

@@ -66,8 +66,11 @@ int do_wait(Fkeep* f) {
     f->hostL_valid = false;
     if (rc == SPLLT_ERROR_NOT_POSDEF) {
       char buf[160];
-      std::snprintf(buf, sizeof buf, "matrix is not positive definite (pivot column %d in elimination order)",
-                    f->eng->not_posdef_column() + 1);
+      if (f->eng->not_posdef_column() < 0)
+        std::snprintf(buf, sizeof buf, "matrix is not positive definite (reported by another rank of the partition)");
+      else
+        std::snprintf(buf, sizeof buf, "matrix is not positive definite (pivot column %d in elimination order)",
+                      f->eng->not_posdef_column() + 1);
       f->last_error = buf;
       std::fprintf(stderr, "spllt-hip: %s\n", buf);
     } else if (rc) {
@@ -90,8 +93,18 @@ int ensure_hostL(Fkeep* f) {
   return 0;
 }
 
+// the SSIDS-style quintuple of spllt_hip_analyse_symbolic (1-based, as SSIDS delivers it)
+struct SymbolicIn {
+  int nnodes;
+  const int* sptr;
+  const int* sparent;
+  const int64_t* rptr;
+  const int* rlist;
+};
+
 void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, const int* ptr,
-                  const int* row, spllt_inform_t* info, int* order, const int* order_in) {
+                  const int* row, spllt_inform_t* info, int* order, const int* order_in,
+                  const SymbolicIn* sym = nullptr) {
   clear_info(info);
   if (!akeep || !fkeep || !options || !ptr || !row || n < 0) {
     std::fprintf(stderr, "spllt-hip: spllt_analyse: invalid argument\n");
@@ -154,7 +167,24 @@ void analyse_impl(void** akeep, void** fkeep, spllt_options_t* options, int n, c
   auto S = std::make_shared<Symbolic>();
   int rc;
   try {
-    rc = analyse(n, p0.data(), r0.data(), order_in ? uo.data() : nullptr, a->so, *S);
+    if (sym) {
+      // 1-based -> 0-based; the virtual root nnodes+1 becomes nnodes
+      const int nn = sym->nnodes;
+      if (nn < 1 || !order_in || !sym->sptr || !sym->sparent || !sym->rptr || !sym->rlist || sym->rptr[0] != 1 ||
+          sym->rptr[nn] < 1) {
+        rc = SPLLT_ERROR_PARAMETER;
+      } else {
+        std::vector<int> sp(nn + 1), spar(nn), rl((size_t)(sym->rptr[nn] - 1));
+        std::vector<int64_t> rp(nn + 1);
+        for (int s = 0; s <= nn; ++s) { sp[s] = sym->sptr[s] - 1; rp[s] = sym->rptr[s] - 1; }
+        for (int s = 0; s < nn; ++s) spar[s] = sym->sparent[s] - 1;
+        for (size_t k = 0; k < rl.size(); ++k) rl[k] = sym->rlist[k] - 1;
+        rc = analyse_symbolic(n, p0.data(), r0.data(), nn, sp.data(), spar.data(), rp.data(), rl.data(),
+                              uo.data(), a->so, *S);
+      }
+    } else {
+      rc = analyse(n, p0.data(), r0.data(), order_in ? uo.data() : nullptr, a->so, *S);
+    }
   } catch (const std::bad_alloc&) {
     rc = SPLLT_ERROR_ALLOCATION;
   }
@@ -235,6 +265,15 @@ void spllt_hip_analyse_ordered(void** akeep, void** fkeep, spllt_options_t* opti
                                const int* ptr, const int* row, spllt_inform_t* info, int* order,
                                const int* order_in) {
   analyse_impl(akeep, fkeep, options, n, ptr, row, info, order, order_in);
+}
+
+void spllt_hip_analyse_symbolic(void** akeep, void** fkeep, spllt_options_t* options, int n,
+                                const int* ptr, const int* row, spllt_inform_t* info, int nnodes,
+                                const int* sptr, const int* sparent, const int64_t* rptr,
+                                const int* rlist, const int* order_in) {
+  SymbolicIn sym{nnodes, sptr, sparent, rptr, rlist};
+  std::vector<int> order_out((size_t)std::max(n, 1));
+  analyse_impl(akeep, fkeep, options, n, ptr, row, info, order_out.data(), order_in, &sym);
 }
 
 void spllt_factor(void* akeep, void* fkeep, spllt_options_t* options, int nnz, double* val,
@@ -555,8 +594,20 @@ int spllt_hip_set_partition(void* fkeep, int rank, int nranks, int64_t* exchange
   std::vector<char> keep;
   int64_t elems = 0;
   partition_tables(f, owner, top, keep, elems);
-  if (exchange_elems) *exchange_elems = nranks > 1 ? elems : 0;
+  // + 1: the element that carries the "not positive definite" indicator across the ranks
+  if (exchange_elems) *exchange_elems = nranks > 1 ? elems + 1 : 0;
   return 0;
+}
+
+void* spllt_hip_engine_stream(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S) return nullptr;
+  if (!f->eng) {   // created here so that the caller can order its collective on it before the first factor
+    f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+    if (!f->eng || f->eng->status()) return nullptr;
+    f->eng->set_exchange_buffer(f->xbuf);
+  }
+  return (void*)f->eng->stream();
 }
 
 int spllt_hip_set_exchange_buffer(void* fkeep, void* dev_ptr) {

@@ -76,6 +76,17 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
         top_bcols_.push_back(b);
         xchg_elems_ += (int64_t)S_->bcols[b].nrow * S_->bcols[b].width;
       }
+    // only the block columns this rank touches (its own branches + the top tree) are cleared
+    // per factorization: the others are never read or written here
+    for (int b = 0; b < S_->nbcol(); ++b) {
+      const int own = owner_[S_->bcols[b].node];
+      if (own != opt_.rank && own >= 0) continue;
+      const int64_t off = S_->bcols[b].off, cnt = (int64_t)S_->bcols[b].nrow * S_->bcols[b].width;
+      if (!zero_ranges_.empty() && zero_ranges_.back().first + zero_ranges_.back().second == off)
+        zero_ranges_.back().second += cnt;
+      else
+        zero_ranges_.push_back({off, cnt});
+    }
   }
   build_program(*S_, so, prog_);
   for (size_t i = 0; i < prog_.launches.size(); ++i)
@@ -133,6 +144,10 @@ int Engine::upload() {
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
   HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "hipMalloc(L arena)");
+  // partitioned: a factorization clears only the block columns this rank touches
+  // (zero_ranges_); the rest is cleared once, here, and never written
+  if (opt_.nranks > 1)
+    HIPCHK(hipMemset(d_L_, 0, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "memset arena");
   HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
   HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)std::max<int64_t>(1, prog_.dinv_size)), "hipMalloc(dinv)");
   if (opt_.nranks > 1) {
@@ -235,7 +250,12 @@ int Engine::finish_enqueue() {
 
 int Engine::enqueue_program() {
   const Symbolic& S = *S_;
-  HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
+  if (opt_.nranks > 1) {
+    for (const auto& r : zero_ranges_)
+      HIPCHK(hipMemsetAsync(d_L_ + r.first, 0, sizeof(double) * (size_t)r.second, stream_), "memset arena");
+  } else {
+    HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
+  }
   const int big = INT_MAX;
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
@@ -260,6 +280,7 @@ int Engine::enqueue_program() {
                           hipMemcpyDeviceToDevice, stream_), "pack top tree");
     xo += cnt;
   }
+  launch_flag_pack(stream_, d_flag_, xbuf_ + xo);
   HIPCHK(hipGetLastError(), "kernel launch");
   awaiting_exchange_ = true;
   return 0;
@@ -283,6 +304,7 @@ int Engine::continue_after_exchange() {
                           hipMemcpyDeviceToDevice, stream_), "unpack top tree");
     xo += cnt;
   }
+  launch_flag_unpack(stream_, xbuf_ + xo, d_flag_);
   const Launch& X = prog_.launches[xchg_idx_];
   if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], stream_), "exchange record");
   int rc = enqueue_range((size_t)xchg_idx_ + 1, prog_.launches.size());
@@ -338,7 +360,7 @@ int Engine::wait() {
   if (hipEventElapsedTime(&ms, ev0_, ev_h2d_) == hipSuccess) stats_.h2d_ms = ms;
   npd_col_ = -1;
   if (*h_flag_ != INT_MAX) {
-    npd_col_ = *h_flag_ - 1;
+    npd_col_ = *h_flag_ == INT_MAX - 1 ? -1 : *h_flag_ - 1;   // -1: reported by another rank
     return kErrNotPosDef;
   }
   return 0;

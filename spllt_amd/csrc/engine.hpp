@@ -57,7 +57,9 @@ class Engine {
   // subtrees with the top-tree block columns packed into the exchange buffer;
   // the caller reduces that buffer across ranks (RCCL all-reduce), then calls
   // continue_after_exchange() and finally wait().
-  int64_t exchange_elems() const { return xchg_elems_; }
+  // doubles of the exchange buffer: the top-tree block columns + one element that carries the
+  // "not positive definite" indicator across the ranks
+  int64_t exchange_elems() const { return xchg_elems_ + 1; }
   int set_exchange_buffer(double* dev_ptr) { xbuf_ = dev_ptr; return 0; }
   bool awaiting_exchange() const { return awaiting_exchange_; }
   int sync_phase();                 // drain the streams at the exchange point
@@ -115,6 +117,7 @@ class Engine {
   std::vector<int> owner_;          // per node: owning rank or -1 (top tree)
   std::vector<int> top_bcols_;      // block columns of the top tree, in order
   std::vector<char> map_keep_;      // per val->L map entry: scattered on this rank?
+  std::vector<std::pair<int64_t, int64_t>> zero_ranges_;  // (offset, count) of the arena this rank clears
   int64_t nmap_ = 0;                // entries of the (filtered) scatter map on the device
   int npd_col_ = -1;
   FactorStats stats_;

@@ -1134,6 +1134,22 @@ void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const do
   hipLaunchKernelGGL(k_winv, dim3((unsigned)count), dim3(kChainThreads), 0, st, units, L, dinv);
 }
 
+// multi-GPU: the "not positive definite" flag travels with the exchange buffer.  Before the
+// exchange every rank appends 1.0 (a pivot of its subtrees failed) or 0.0; after the sum
+// over the ranks a non-zero entry marks the factorization as failed on EVERY rank.
+__global__ void k_flag_pack(const int* __restrict__ flag, double* __restrict__ slot) {
+  *slot = (*flag != 0x7fffffff) ? 1.0 : 0.0;
+}
+__global__ void k_flag_unpack(const double* __restrict__ slot, int* __restrict__ flag) {
+  if (*slot > 0.5 && *flag == 0x7fffffff) *flag = 0x7ffffffe;   // failed on another rank
+}
+void launch_flag_pack(hipStream_t st, const int* flag, double* slot) {
+  hipLaunchKernelGGL(k_flag_pack, dim3(1), dim3(1), 0, st, flag, slot);
+}
+void launch_flag_unpack(hipStream_t st, const double* slot, int* flag) {
+  hipLaunchKernelGGL(k_flag_unpack, dim3(1), dim3(1), 0, st, slot, flag);
+}
+
 // debug aid (engine flag 128): one workgroup per CU-sized LDS allocation writes a
 // signalling-NaN pattern over all 160 KB, so that any kernel that later reads LDS it
 // has not written computes with NaNs instead of with whatever the previous kernel left

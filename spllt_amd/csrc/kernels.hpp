@@ -19,6 +19,9 @@ void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, i
                         double* L, double* dinv, int* flag);
 // W part of Winv of the same units (side stream)
 void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv);
+// multi-GPU: not-positive-definite flag <-> extra element of the exchange buffer
+void launch_flag_pack(hipStream_t st, const int* flag, double* slot);
+void launch_flag_unpack(hipStream_t st, const double* slot, int* flag);
 // debug: fill the LDS of every CU with signalling NaNs
 void launch_poison_lds(hipStream_t st);
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,

@@ -424,6 +424,17 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
   }
   S.order = order;
   S.porder = porder;
+  return finish_symbolic(n, ptr, row, &xadj, &adj, opt, S);
+}
+
+// Everything SpLLT derives from the symbolic quintuple (order, sptr, sparent [, rptr, rlist]):
+// tree arrays, schedule levels, row lists (computed here unless S already carries them),
+// flop weights, pruning, tile layout, the val -> L map.  Shared by the built-in analyse and
+// by analyse_symbolic (the quintuple SpLLT takes from SSIDS, analyse_mod:155-158).
+int finish_symbolic(int n, const int64_t* ptr, const int* row, const std::vector<int64_t>* xadj_p,
+                    const std::vector<int>* adj_p, const SymOptions& opt, Symbolic& S) {
+  const std::vector<int>& order = S.order;
+  const std::vector<int>& porder = S.porder;
   const int nn = S.nnodes;
   S.snode_of.assign(n, 0);
   for (int s = 0; s < nn; ++s)
@@ -464,6 +475,9 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
     for (int s = 0; s < nn; ++s) S.level[s] -= mn;
   }
 
+  if (S.rlist.empty()) {
+    const std::vector<int64_t>& xadj = *xadj_p;
+    const std::vector<int>& adj = *adj_p;
   // ---- row lists (supernodal symbolic factorisation) -------------------
   S.rptr.assign(nn + 1, 0);
   {
@@ -492,6 +506,8 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
       for (int j = c0; j < c1; ++j) S.rlist.push_back(j);
       S.rlist.insert(S.rlist.end(), tmp.begin(), tmp.end());
     }
+  }
+
   }
 
   // ---- flop weights (spllt_symbolic) -----------------------------------
@@ -567,13 +583,74 @@ int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
         const BlockCol& B = S.bcols[bc];
         const int* rows = S.rows(s);
         int lr = (int)(std::lower_bound(rows, rows + S.nrow(s), r) - rows);
-        if (lr >= S.nrow(s) || rows[lr] != r) return -99;  // structure bug
+        if (lr >= S.nrow(s) || rows[lr] != r) return S.ordering == "symbolic" ? -10 : -99;  // row lists do not cover A
         int64_t k = pos[bc]++;
         S.map_dst[k] = B.off + (int64_t)(lr - B.r0) * B.width + (col - S.sptr[s] - B.r0);
         S.map_src[k] = e;
       }
   }
   return 0;
+}
+
+int analyse_symbolic(int n, const int64_t* ptr, const int* row, int nnodes, const int* sptr,
+                     const int* sparent, const int64_t* rptr, const int* rlist, const int* order,
+                     const SymOptions& opt, Symbolic& S) {
+  S = Symbolic();
+  S.n = n;
+  S.nb = opt.nb < 1 ? 256 : opt.nb;
+  if (n <= 0) return n == 0 ? 0 : -10;
+  if (nnodes < 1 || !sptr || !sparent || !rptr || !rlist || !order) return -10;
+  S.nnzA = ptr[n];
+  for (int j = 0; j < n; ++j)
+    for (int64_t e = ptr[j]; e < ptr[j + 1]; ++e)
+      if (row[e] < 0 || row[e] >= n) return -10;
+  // order: a permutation; nodes: postordered (parent > child), contiguous column ranges
+  S.order.assign(order, order + n);
+  S.porder.assign(n, -1);
+  for (int i = 0; i < n; ++i) {
+    const int p = order[i];
+    if (p < 0 || p >= n || S.porder[p] >= 0) return -10;
+    S.porder[p] = i;
+  }
+  if (sptr[0] != 0 || sptr[nnodes] != n || rptr[0] != 0) return -10;
+  for (int s = 0; s < nnodes; ++s) {
+    if (sptr[s + 1] <= sptr[s]) return -10;
+    if (sparent[s] <= s || sparent[s] > nnodes) return -10;
+    const int nc = sptr[s + 1] - sptr[s];
+    const int64_t m = rptr[s + 1] - rptr[s];
+    if (m < nc) return -10;
+    const int* r = rlist + rptr[s];
+    for (int64_t k = 0; k < m; ++k) {
+      if (r[k] < 0 || r[k] >= n) return -10;
+      if (k < nc ? r[k] != sptr[s] + (int)k : r[k] <= r[k - 1]) return -10;   // own columns first, sorted
+    }
+  }
+  // every row below a node's own columns must also be a row of its parent (the fill of the
+  // child lands there): the factorization indexes the parent's row list with the child's rows
+  for (int s = 0; s < nnodes; ++s) {
+    const int p = sparent[s];
+    const int nc = sptr[s + 1] - sptr[s];
+    const int64_t m = rptr[s + 1] - rptr[s];
+    if (p >= nnodes) {
+      if (m != nc) return -10;   // a root has no rows below its columns
+      continue;
+    }
+    const int* pr = rlist + rptr[p];
+    const int64_t pm = rptr[p + 1] - rptr[p];
+    int64_t q = 0;
+    for (int64_t k = nc; k < m; ++k) {
+      const int r = rlist[rptr[s] + k];
+      while (q < pm && pr[q] < r) ++q;
+      if (q >= pm || pr[q] != r) return -10;
+    }
+  }
+  S.ordering = "symbolic";
+  S.nnodes = nnodes;
+  S.sptr.assign(sptr, sptr + nnodes + 1);
+  S.sparent.assign(sparent, sparent + nnodes);
+  S.rptr.assign(rptr, rptr + nnodes + 1);
+  S.rlist.assign(rlist, rlist + rptr[nnodes]);
+  return finish_symbolic(n, ptr, row, nullptr, nullptr, opt, S);
 }
 
 }  // namespace spx

@@ -48,7 +48,7 @@ struct Symbolic {
   int64_t nnzA = 0;
   int nnodes = 0;
   int nb = 0;
-  std::string ordering;  // "nd-bfs" | "user"
+  std::string ordering;  // "nd-bfs" | "user" | "symbolic"
 
   std::vector<int> order;    // order[var] = pivot position
   std::vector<int> porder;   // porder[pos] = var
@@ -93,6 +93,17 @@ struct Symbolic {
 // built-in nested dissection.  Returns 0 or a negative SpLLT error flag.
 int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
             const SymOptions& opt, Symbolic& S);
+
+// Analyse from a caller-supplied symbolic factorization -- the quintuple SpLLT takes from
+// SSIDS (reference src/spllt_analyse_mod.F90:129-158): all 0-based here; order[var] = pivot
+// position, nodes postordered with contiguous column ranges sptr, sparent[s] > s (== nnodes
+// for roots), row lists sorted with the node's own columns first.  No supernode detection,
+// amalgamation or reordering happens: the factorization uses exactly this partition.
+int analyse_symbolic(int n, const int64_t* ptr, const int* row, int nnodes, const int* sptr,
+                     const int* sparent, const int64_t* rptr, const int* rlist, const int* order,
+                     const SymOptions& opt, Symbolic& S);
+int finish_symbolic(int n, const int64_t* ptr, const int* row, const std::vector<int64_t>* xadj,
+                    const std::vector<int>* adj, const SymOptions& opt, Symbolic& S);
 
 // Exposed for tests.
 void nested_dissection(int n, const std::vector<int64_t>& xadj,

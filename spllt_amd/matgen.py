@@ -152,6 +152,107 @@ def read_mtx(path):
     return A
 
 
+def _fortran_fields(fmt):
+    """(count, width) of a Rutherford-Boeing Fortran format such as (10I8),
+    (1P,3E25.16), (4D20.12) or (8F10.3): fields are fixed-width and may abut"""
+    import re
+    m = re.search(r"(\d+)\s*[IiEeDdFfGg]\s*(\d+)", fmt.replace(" ", ""))
+    if not m:
+        raise ValueError(f"unsupported Fortran format {fmt!r}")
+    return int(m.group(1)), int(m.group(2))
+
+
+def _read_fixed(lines, pos, nlines, fmt, count, conv):
+    per, width = _fortran_fields(fmt)
+    out = []
+    for ln in lines[pos:pos + nlines]:
+        ln = ln.rstrip("\n")
+        for k in range(per):
+            if len(out) == count:
+                break
+            fld = ln[k * width:(k + 1) * width]
+            if fld.strip():
+                out.append(conv(fld))
+    if len(out) != count:
+        raise ValueError(f"expected {count} entries, found {len(out)}")
+    return out
+
+
+def read_rb(path, values=3, seed=1):
+    """Rutherford-Boeing reader for assembled symmetric matrices (type ?sa: rsa / psa /
+    isa), the 'csc' input of the reference's drivers (drivers/spllt_omp.F90:78-85, SPRAL
+    rb_read).  `values` follows the driver's use of rb_options%values:
+      0  values as in the file (a pattern-only file is an error),
+      3  what every reference driver asks for ("force diagonal dominance"): keep the
+         file's off-diagonal values, or invent them (uniform in (-1, 1), fixed seed --
+         the reference uses SPRAL's random_real for missing values,
+         src/spllt_mod.F90:480-485) when the file holds a pattern only, then set every
+         diagonal entry to 1 + sum |off-diagonal entries of its row| so that the matrix
+         is strictly diagonally dominant, hence positive definite.
+    Returns the full symmetric matrix as scipy CSC."""
+    with open(path) as fh:
+        lines = fh.readlines()
+    if len(lines) < 4:
+        raise ValueError("not a Rutherford-Boeing file")
+    cards = lines[1].split()
+    totcrd, ptrcrd, indcrd = int(cards[0]), int(cards[1]), int(cards[2])
+    valcrd = int(cards[3]) if len(cards) > 3 else totcrd - ptrcrd - indcrd
+    l3 = lines[2].split()
+    mxtype = l3[0].lower()
+    nrow, ncol, nnz = int(l3[1]), int(l3[2]), int(l3[3])
+    if len(mxtype) != 3 or mxtype[1] != "s" or mxtype[2] != "a" or nrow != ncol:
+        raise ValueError(f"only assembled symmetric matrices (?sa) are supported, got {mxtype!r}")
+    fm = lines[3]
+    ptrfmt, indfmt = fm[:16], fm[16:32]
+    valfmt = fm[32:52] if len(fm) > 32 else ""
+    pos = 4
+    ptr = np.array(_read_fixed(lines, pos, ptrcrd, ptrfmt, ncol + 1, int), dtype=np.int64) - 1
+    pos += ptrcrd
+    ind = np.array(_read_fixed(lines, pos, indcrd, indfmt, nnz, int), dtype=np.int64) - 1
+    pos += indcrd
+    has_values = mxtype[0] in "ri" and valcrd > 0
+    if has_values:
+        val = np.array(_read_fixed(lines, pos, valcrd, valfmt, nnz,
+                                   lambda t: float(t.replace("D", "E").replace("d", "e"))))
+    elif values == 0:
+        raise ValueError("pattern-only file and values=0")
+    else:
+        val = np.random.default_rng(seed).uniform(-1.0, 1.0, size=nnz)
+    if ptr[0] != 0 or ptr[-1] != nnz or (np.diff(ptr) < 0).any() or ind.min() < 0 or ind.max() >= nrow:
+        raise ValueError("inconsistent column pointers / row indices")
+    L = sp.csc_matrix((val, ind, ptr), shape=(nrow, ncol))
+    L = sp.tril(L, format="csc")                  # stored triangle (lower by convention)
+    A = (L + sp.tril(L, -1).T).tocsc()
+    if values == 3:
+        off = (A - sp.diags(A.diagonal())).tocsc()
+        diag = 1.0 + np.asarray(abs(off).sum(axis=1)).ravel()
+        A = (off + sp.diags(diag)).tocsc()
+    A.sort_indices()
+    return A
+
+
+def write_rb(path, A, pattern_only=False, title="spllt-hip test matrix", key="SPLLTHIP"):
+    """Writes the lower triangle of a symmetric matrix as an rsa / psa Rutherford-Boeing
+    file (used by the tests of read_rb)."""
+    L = sp.tril(sp.csc_matrix(A), format="csc")
+    L.sort_indices()
+    n, nnz = L.shape[0], L.nnz
+
+    def cards(vals, per, fmt):
+        vals = list(vals)
+        return ["".join(fmt % v for v in vals[i:i + per]) for i in range(0, len(vals), per)]
+    pl = cards(L.indptr + 1, 8, "%10d")
+    il = cards(L.indices + 1, 8, "%10d")
+    vl = [] if pattern_only else cards(L.data, 3, "%26.17E")
+    with open(path, "w") as fh:
+        fh.write(f"{title:<72}{key:<8}\n")
+        fh.write(f"{len(pl) + len(il) + len(vl):14d}{len(pl):14d}{len(il):14d}{len(vl):14d}\n")
+        fh.write(f"{'psa' if pattern_only else 'rsa':<14}{n:14d}{n:14d}{nnz:14d}{0:14d}\n")
+        fh.write(f"{'(8I10)':<16}{'(8I10)':<16}{'' if pattern_only else '(3E26.17)':<20}\n")
+        for ln in pl + il + vl:
+            fh.write(ln + "\n")
+
+
 def make_diag_dominant(A):
     """Replace the values by a diagonally dominant set on the same pattern
     (what SPRAL's rb_read does for values=3, as used by every reference driver)."""

@@ -10,7 +10,8 @@ and accumulates its contributions to the
 top tree in its own (zero-initialised) copy of the top-tree block columns.  The
 extend-add of the reference -- generated element + spllt_scatter_block
 (src/spllt_factorization_mod.F90:39-191, src/spllt_kernels_mod.F90:1122-1160)
--- becomes ONE all-reduce(sum) of that arena slice over xGMI; the top tree is
+-- becomes ONE all-reduce(sum) of that arena slice over xGMI, enqueued on the
+engine's own stream (no host synchronisation between the phases); the top tree is
 then factorized on every rank (v1: replicated; SURVEY 8(e) "top tree v1").
 
 torch is used only for device memory and torch.distributed (plumbing).
@@ -37,34 +38,59 @@ class DistributedFactorization:
     def __init__(self, n, ptr, row, nb, rank, world, order=None, nemin=32, panel_width=None,
                  group=None):
         import torch
+        import torch.distributed as dist
         from . import api
         self.rank, self.world, self.group = rank, world, group
         self.f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=world > 1,
                                    ncpu=world, order=order, panel_width=panel_width)
         self.xelems = self.f.set_partition(rank, world) if world > 1 else 0
         self.xbuf = torch.zeros(max(self.xelems, 1), dtype=torch.float64, device="cuda")
+        self.ext = None
         if world > 1:
             self.f.set_exchange_buffer(self.xbuf.data_ptr())
+            # the engine's own stream as a torch stream: collectives enqueued under it are
+            # ordered behind the pack and in front of the unpack without a host round trip
+            self.ext = torch.cuda.ExternalStream(self.f.engine_stream())
+        self.stream_ordered = (world > 1 and dist.is_initialized() and
+                               dist.get_backend(group) == "nccl")
         self.phase_ms = {}
 
-    def factor(self, dval):
-        """One complete distributed factorization (dval: cuda float64 tensor)."""
+    def _exchange(self):
+        """extend-add of the top-tree block columns (+ the not-positive-definite
+        indicator): one all-reduce(sum) on the engine's stream"""
         import torch
-        t0 = time.perf_counter()
-        self.f.factor_dev(dval.data_ptr())
-        self.f.wait()                      # own subtrees done, top tree packed
-        t1 = time.perf_counter()
-        if self.world > 1:
+        if self.stream_ordered:
+            with torch.cuda.stream(self.ext):
+                reduce_exchange_buffer(self.xbuf, self.group)   # RCCL: enqueue only
+        else:
+            # gloo (CPU tests / one-GPU rehearsal) stages through the host: plain syncs
+            self.ext.synchronize()
             reduce_exchange_buffer(self.xbuf, self.group)
             torch.cuda.synchronize()
-            t2 = time.perf_counter()
+
+    def factor(self, dval, timed_phases=False):
+        """One complete distributed factorization (dval: cuda float64 tensor).  The three
+        phases -- own subtrees, exchange, top tree -- are enqueued back to back on the
+        engine's stream; the host only waits at the end (timed_phases=True adds a host
+        synchronisation after each phase to time it).  A pivot failure on any rank raises
+        the same SplltError(-20) on every rank after the last phase."""
+        t0 = time.perf_counter()
+        self.f.factor_dev(dval.data_ptr())
+        t1 = t2 = t0
+        if self.world > 1:
+            if timed_phases:
+                self.ext.synchronize()
+                t1 = time.perf_counter()
+            self._exchange()
+            if timed_phases:
+                self.ext.synchronize()
+                t2 = time.perf_counter()
             self.f.continue_after_exchange()
-            self.f.wait()                  # replicated top tree done
-        else:
-            t2 = t1
+        self.f.wait()
         t3 = time.perf_counter()
-        self.phase_ms = {"subtrees": (t1 - t0) * 1e3, "exchange": (t2 - t1) * 1e3,
-                         "top": (t3 - t2) * 1e3}
+        if timed_phases or self.world == 1:
+            self.phase_ms = {"subtrees": (t1 - t0) * 1e3, "exchange": (t2 - t1) * 1e3,
+                             "top": (t3 - t2) * 1e3}
         return self
 
     def owned_mask(self):
@@ -140,49 +166,36 @@ def _timed(df, dval, steps, active):
 def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
     """bench.py body for N > 1 (strong scaling: one factorization, N GPUs).
 
-    The tree-level partition has one knob, its width w <= N (the
-    subtrees shard, the top tree does not): w ranks own subtrees and run the
-    exchange, the others idle.  A wider partition shortens the subtree phase
-    but grows the replicated top tree and the exchange, so the width is
-    measured, not assumed: every power of two w <= N (and N) is timed during
-    warm-up and the fastest one runs the timed steps."""
+    `value` is ALWAYS the run that uses all N ranks (partition width = N).  The
+    tree-level partition could also be run narrower (w < N ranks own subtrees, the
+    others idle: a wider partition shortens the subtree phase but grows the replicated
+    top tree and the exchange); with SPLLT_WIDTH_SWEEP=1 the narrower widths are timed
+    too and reported under detail.width_trials_ms -- never as `value`."""
     import torch
     import torch.distributed as dist
-    widths = sorted({w for w in (1, 2, 4, 8, 16, world) if w <= world})
-    forced = int(os.environ.get("SPLLT_PARTITION_WIDTH", "0"))
-    if forced:
-        widths = [min(max(forced, 1), world)]
     dval = torch.tensor(val, device="cuda")
-    trial, groups = {}, {}
-    best_w, best_t = None, None
-    for w in widths:
-        # every width is tried alone on the device: engines that share the heap with
-        # others can land on fragmented memory and run 2x slower, which would bias
-        # the comparison
-        groups[w] = dist.new_group(ranks=list(range(w))) if 1 < w < world else None
-        active = rank < w
-        df = None
-        if active:
-            df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
-                                          panel_width=args.panel, group=groups[w])
-        _timed(df, dval, 1, active)                      # first touch
-        t = _timed(df, dval, max(1, args.warmup), active) / max(1, args.warmup)
-        trial[w] = round(t * 1e3, 3)
-        if best_t is None or t < best_t:
-            best_w, best_t = w, t
-        if df is not None and len(widths) > 1:
-            df.close()
+    trial = {}
+    if os.environ.get("SPLLT_WIDTH_SWEEP"):
+        for w in sorted({w for w in (1, 2, 4, 8) if w < world}):
+            grp = dist.new_group(ranks=list(range(w))) if w > 1 else None
+            active = rank < w
             df = None
+            if active:
+                df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
+                                              panel_width=args.panel, group=grp)
+            _timed(df, dval, 1, active)                      # first touch
+            t = _timed(df, dval, max(1, args.warmup), active) / max(1, args.warmup)
+            trial[w] = round(t * 1e3, 3)
+            if df is not None:
+                df.close()
             torch.cuda.empty_cache()
-    w = best_w
-    active = rank < w
-    if len(widths) > 1:
-        df = None
-        if active:
-            df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order,
-                                          panel_width=args.panel, group=groups[w])
-        _timed(df, dval, 1, active)
-    t_total = _timed(df, dval, args.steps, active)
+    w = world
+    df = DistributedFactorization(n, ptr, row, nb, rank, w, order=order, panel_width=args.panel)
+    for _ in range(max(1, args.warmup)):
+        _timed(df, dval, 1, True)
+    t_total = _timed(df, dval, args.steps, True)
+    trial[w] = round(t_total / args.steps * 1e3, 3)
+    df.factor(dval, timed_phases=True)       # one more, untimed for `value`: per-phase times
     si_t = torch.zeros(4, dtype=torch.float64, device="cuda")
     if rank == 0:
         si = df.f.sym_info()
@@ -190,7 +203,7 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
                             device="cuda")
     flops = float(si_t[0].item()) if rank == 0 else 0.0
     check, own_w, top_flops = {}, np.zeros(max(w, 1)), 0.0
-    if active and w > 1:
+    if w > 1:
         # flops of the branches each rank owns = subtree weights of their roots
         owner, wgt, par = df.f.partition("owner"), df.f.sym("weight"), df.f.sym("sparent")
         nn = len(owner)
@@ -199,7 +212,10 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
                 own_w[owner[s]] += wgt[s]
         top_flops = float(df.f.sym_info()["flops"]) - own_w.sum()
     if not args.no_check:
-        check = _accuracy_gate(df, A, n, rank, w, active)
+        check = _accuracy_gate(df, A, n, rank, w, True)
+    extra = None
+    if not os.environ.get("SPLLT_NO_BASELINE_CONFIG"):
+        extra = _baseline_config_for(world, args, rank)
     out = None
     if rank == 0:
         out = {
@@ -210,15 +226,45 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "n": n, "nb": nb, "nnz_L": int(si_t[1].item()),
                        "flops_sym": flops, "nnodes": int(si_t[2].item()),
-                       "parallelism": f"subtree partition of width {w} over {world} GPUs (width "
-                                      "measured during warm-up) + RCCL all-reduce extend-add, "
-                                      "replicated top tree"},
+                       "parallelism": f"subtree partition over all {world} GPUs + one RCCL all-reduce "
+                                      "(extend-add) on the engine's stream, replicated top tree"},
             "roofline": None, "cpu_baseline": None,
             "detail": {"partition_width": w, "width_trials_ms": trial,
                        "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
                        "subtree_gflop_per_rank": (own_w / 1e9).round(1).tolist(),
-                       "top_tree_gflop": round(top_flops / 1e9, 1), "check": check},
+                       "top_tree_gflop": round(top_flops / 1e9, 1), "check": check,
+                       "baseline_config_for_this_n": extra},
         }
+    return out
+
+
+# BASELINE.json names a configuration per GPU count: Flan_1565 on 2 and 4, Serena on 8
+BASELINE_CONFIG_FOR_N = {2: "flan_like", 4: "flan_like", 8: "serena_like"}
+
+
+def _baseline_config_for(world, args, rank):
+    """Times the configuration BASELINE.json quotes for this GPU count (stand-in matrices)
+    with the same engine: reported under detail, never as `value`."""
+    import torch
+    from . import api, matgen
+    cfg_name = BASELINE_CONFIG_FOR_N.get(world)
+    if cfg_name is None:
+        return None
+    A, order, cfg = matgen.build_config(cfg_name, 1.0)
+    n, ptr, row, val = api.csc_lower_1based(A)
+    dval = torch.tensor(val, device="cuda")
+    df = DistributedFactorization(n, ptr, row, cfg["nb"], rank, world, order=order)
+    _timed(df, dval, 1, True)
+    steps = 2
+    t = _timed(df, dval, steps, True) / steps
+    df.factor(dval, timed_phases=True)
+    si = df.f.sym_info()
+    out = {"workload": cfg_name, "n": n, "nb": cfg["nb"], "flops_sym": float(si["flops"]),
+           "ms_per_step": round(t * 1e3, 2), "gflops": round(float(si["flops"]) / t / 1e9, 1),
+           "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6}
+    df.close()
+    del dval
+    torch.cuda.empty_cache()
     return out
 
 

@@ -52,7 +52,8 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             top = f.partition("top_bcols")
             sl_ = [slice(int(bc_off[b]), int(bc_off[b]) + int(bc_nrow[b]) * int(bc_w[b]))
                    for b in top]
-            xbuf = np.concatenate([arena[s_] for s_ in sl_]) if sl_ else np.zeros(0)
+            # + one element: the "not positive definite" indicator (0 = this rank is fine)
+            xbuf = np.concatenate([arena[s_] for s_ in sl_] + [np.zeros(1)])
             xbuf = exchange(xbuf)
             o = 0
             for s_ in sl_:

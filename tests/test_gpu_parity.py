@@ -310,6 +310,23 @@ def test_fortran_api_kat():
     assert "1.50000000  2.00000000  1.50000000" in r.stdout
 
 
+def test_c_caller_inside_omp_parallel_single():
+    """The C-ABI in its documented calling context (reference example/C/simple.c:52-75):
+    analyse / factor / wait / solve / chkerr issued from inside `#pragma omp parallel` +
+    `single` by whichever thread won the single, a second factorization submitted by
+    another thread of the team (spllt_amd/c/omp_caller.c, built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spllt_amd", "c",
+                       "omp_caller")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    for threads, g in (("4", "40"), ("7", "25")):
+        r = subprocess.run([exe, g], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, OMP_NUM_THREADS=threads))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"team={threads}" in r.stdout and "fail=0" in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_engine_two_ranks_on_one_gpu(world):
     """Multi-GPU engine path on the one-GPU box: `world` rank-engines run in
@@ -401,6 +418,45 @@ def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None):
     with pytest.raises(api.SplltError) as ei:      # spllt_solve needs the caller's exchange
         fs[0].solve(B[:, 0])
     assert ei.value.flag == -98
+    for f in fs:
+        f.close()
+
+
+def test_partitioned_not_posdef_is_reported_on_every_rank():
+    """A non-positive pivot inside ONE rank's subtree: the indicator travels with the
+    exchange buffer, so every rank-engine reports SPLLT_ERROR_NOT_POSDEF (-20) after the
+    top tree instead of factorizing a garbage top tree and returning success."""
+    torch = _torch()
+    A = matgen.poisson2d(24).tolil()
+    world = 2
+    fs, bufs = [], []
+    for r in range(world):
+        f, val = make_case(A.tocsc(), nb=16, nemin=8, prune=True, ncpu=world)
+        xb = torch.zeros(f.set_partition(r, world), dtype=torch.float64, device="cuda")
+        f.set_exchange_buffer(xb.data_ptr())
+        fs.append(f)
+        bufs.append(xb)
+    # break a diagonal entry that lives in a subtree owned by rank 1
+    owner, sptr, order = fs[0].partition("owner"), fs[0].sym("sptr"), fs[0].sym("order")
+    node_of_pos = np.repeat(np.arange(len(sptr) - 1), np.diff(sptr))
+    var = int(np.nonzero(owner[node_of_pos[order]] == 1)[0][0])
+    A[var, var] = -5.0
+    n, ptr, row, val = api.csc_lower_1based(A.tocsc())
+    dval = torch.tensor(val, device="cuda")
+    torch.cuda.synchronize()
+    for f in fs:
+        f.factor_dev(dval.data_ptr())
+        f.wait()          # phase 1 only drains the streams: no error yet
+    total = torch.stack(bufs).sum(dim=0)
+    assert total[-1].item() == 1.0        # exactly one rank raised the indicator
+    for xb in bufs:
+        xb.copy_(total)
+    torch.cuda.synchronize()
+    for r, f in enumerate(fs):
+        f.continue_after_exchange()
+        with pytest.raises(api.SplltError) as e:
+            f.wait()
+        assert e.value.flag == -20, r
     for f in fs:
         f.close()
 

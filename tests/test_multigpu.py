@@ -101,3 +101,52 @@ def test_owner_assignment_is_balanced_and_covers_subtrees():
         assert (owner == -1).any() and load.min() > 0.25 * load.max(), (world, load)
         # the top tree is what spans several ranks: far fewer nodes than the branches
         assert (owner == -1).sum() < 0.25 * nn
+
+
+def _gpu_worker(rank, world, port, ret):
+    """one process per rank, every rank on device 0, reduction over gloo: the production
+    DistributedFactorization (factor with the exchange on the engine's stream, then the
+    three-phase solve) end to end"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spllt_amd import api, matgen, multigpu
+        A = matgen.nd_like((11, 10, 9), 2)
+        n, ptr, row, val = api.csc_lower_1based(A)
+        df = multigpu.DistributedFactorization(n, ptr, row, 48, rank, world, nemin=16)
+        dval = torch.tensor(val, device="cuda")
+        torch.cuda.synchronize()
+        df.factor(dval)
+        df.factor(dval, timed_phases=True)          # re-factorization, with per-phase syncs
+        rng = np.random.default_rng(11)
+        X = rng.standard_normal((n, 3))
+        B = A @ X
+        got = df.solve(B)
+        r = B - A @ got
+        bwd = max(float(np.linalg.norm(r[:, q]) / (np.linalg.norm(B[:, q]) + abs(A).max() * np.linalg.norm(got[:, q])))
+                  for q in range(3))
+        ret[rank] = (bwd, float(np.abs(got - X).max()), sorted(df.phase_ms))
+        df.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_factorization_two_processes_one_gpu():
+    import torch.multiprocessing as mp
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank in range(world):
+        bwd, err, phases = ret[rank]
+        assert bwd <= 1e-14 and err <= 1e-9, (rank, bwd, err)
+        assert phases == ["exchange", "subtrees", "top"]
