@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--config", default="nd24k_like", help="matgen.CONFIGS key")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every grid edge (debug)")
     ap.add_argument("--mm", default=None, help="MatrixMarket file to use instead of the stand-in")
+    ap.add_argument("--rb", default=None, help="Rutherford-Boeing file (values = 3 conditioning, like the reference drivers)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the other BASELINE configurations reported under detail.configs")
     ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"])
     ap.add_argument("--nb", type=int, default=None)
     ap.add_argument("--panel", type=int, default=None)
@@ -51,6 +54,10 @@ def build_workload(args):
         A = matgen.make_diag_dominant(matgen.read_mtx(args.mm))
         order, cfg = None, dict(nb=args.nb or 256, gen="mtx:" + os.path.basename(args.mm))
         name = "mtx:" + os.path.basename(args.mm)
+    elif args.rb:
+        A = matgen.read_rb(args.rb, values=3)
+        order, cfg = None, dict(nb=args.nb or 256, gen="rb:" + os.path.basename(args.rb))
+        name = "rb:" + os.path.basename(args.rb)
     else:
         A, order, cfg = matgen.build_config(args.config, args.scale)
         name = args.config + ("" if args.scale == 1.0 else f"@{args.scale}")
@@ -67,30 +74,75 @@ UPDATE_KERNELS = {128: "k_update<128, 16, 4, 2>", 64: "k_update<64, 16, 2, 2>", 
 def roofline_from_profile(f, val):
     """Dominant kernel = the k_update<T,...> instantiation (fp64 MFMA GEMM with
     direct / scatter / TRSM epilogue) with the largest total time.  achieved =
-    algorithmic flops of all its launches / the sum of their durations, measured
-    with HIP events on the engine's own stream."""
+    algorithmic flops of all its launches / the sum of their durations, measured live with
+    HIP events on the stream each launch runs on.  Two figures:
+      frac            launches serialized on one stream: the kernel alone on the chip
+      frac_in_program the same launches inside the real multi-stream program (beside the
+                      panel chains and the other update streams): what the program gets"""
     # two passes, per-launch minimum: a single pass occasionally shows one launch
     # stalled by tens of ms (host/driver hiccup between its two event records)
     ms = np.minimum(f.profile(val), f.profile(val))
+    ms_prog = np.minimum(f.profile(val, in_program=True), f.profile(val, in_program=True))
     L = f.program("launches")
     kinds, tiles, flops = L[:, 0], L[:, 4], L[:, 5].astype(np.float64)
-    table = {"potrf_ms": float(ms[kinds == 0].sum()), "potrf_launches": int((kinds == 0).sum()),
+    table = {"chain_ms": float(ms[kinds == 4].sum()), "chain_launches": int((kinds == 4).sum()),
+             "chain_ms_in_program": float(ms_prog[kinds == 4].sum()),
              "total_ms": float(ms.sum()), "total_gflop": float(flops.sum()) / 1e9}
     per = {}
     for T in UPDATE_KERNELS:
-        sel = (kinds == 1) & (tiles == T)
-        per[T] = (float(ms[sel].sum()), float(flops[sel].sum()), int(sel.sum()))
+        sel = (kinds == 1) & (tiles == T) & (L[:, 3] > 0)
+        per[T] = (float(ms[sel].sum()), float(flops[sel].sum()), int(sel.sum()), float(ms_prog[sel].sum()))
         table[f"update{T}_ms"], table[f"update{T}_gflop"], table[f"update{T}_launches"] = (
             per[T][0], per[T][1] / 1e9, per[T][2])
         table[f"update{T}_tflops"] = round(per[T][1] / per[T][0] / 1e9, 2) if per[T][0] > 0 else 0.0
+        table[f"update{T}_tflops_in_program"] = round(per[T][1] / per[T][3] / 1e9, 2) if per[T][3] > 0 else 0.0
     T = max(per, key=lambda t: per[t][0])
-    t_s, fl, nl = per[T][0] * 1e-3, per[T][1], per[T][2]
+    t_s, fl, nl, t_prog = per[T][0] * 1e-3, per[T][1], per[T][2], per[T][3] * 1e-3
     ach = fl / t_s / 1e12 if t_s > 0 else 0.0
+    ach_prog = fl / t_prog / 1e12 if t_prog > 0 else 0.0
     roof = {"bound": "mfma", "kernel": UPDATE_KERNELS[T], "achieved": round(ach, 3),
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launches": nl, "avg_launch_ms": round(per[T][0] / max(nl, 1), 4)}
+            "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
+            "achieved_in_program": round(ach_prog, 3),
+            "frac_in_program": round(ach_prog / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": nl, "avg_launch_ms": round(per[T][0] / max(nl, 1), 4),
+            "avg_launch_ms_in_program": round(per[T][3] / max(nl, 1), 4)}
     return roof, table, ms
+
+
+def run_extra_config(cfg_name, steps=2):
+    """One of the other BASELINE.json configurations with the same engine, reported under
+    detail.configs (never as `value`): resident GFLOP/s, accuracy, dominant-kernel rate."""
+    import torch
+    from spllt_amd import api, matgen
+    A, order, cfg = matgen.build_config(cfg_name, 1.0)
+    if cfg_name == "poisson3d_128":
+        order = None            # BASELINE.md: built-in nested dissection for config 3
+    n, ptr, row, val = api.csc_lower_1based(A)
+    f = api.Factorization(n, ptr, row, nb=cfg["nb"], nemin=32, prune_tree=False, order=order)
+    si = f.sym_info()
+    flops = float(si["flops"])
+    dval = torch.tensor(val, device="cuda")
+    torch.cuda.synchronize()
+    f.factor_dev(dval.data_ptr()).wait()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f.factor_dev(dval.data_ptr()).wait()
+    t = (time.perf_counter() - t0) / steps
+    b = A @ np.ones(n)
+    x = f.solve(b)
+    r = b - A @ x
+    roof, table, _ = roofline_from_profile(f, val)
+    out = {"workload": cfg_name, "n": n, "nb": cfg["nb"], "nnz_L": int(si["nnz_l"]), "flops_sym": flops,
+           "ms_per_step": round(t * 1e3, 2), "gflops": round(flops / t / 1e9, 1),
+           "resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
+           "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x))),
+           "dominant_kernel": roof["kernel"], "dominant_tflops": roof["achieved"],
+           "dominant_frac": roof["frac"], "dominant_frac_in_program": roof["frac_in_program"]}
+    f.close()
+    del dval
+    torch.cuda.empty_cache()
+    return out
 
 
 def host_cores(cap=16):
@@ -205,13 +257,13 @@ def main():
     # inside this process); the committed summary is quoted when it was taken
     # on this very workload.
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")) as fh:
             pmc = json.load(fh)
         k = pmc.get("kernels", {}).get(roof["kernel"])
         if pmc.get("workload") == name and k:
             roof["traffic"] = round(k["hbm_bytes_per_launch"])
             roof["traffic_unit"] = ("bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                                    "profiles/r01/pmc_summary.json)")
+                                    "profiles/r02/pmc_summary.json)")
             roof["algorithmic_bytes_per_launch"] = round(k["algorithmic_bytes_per_launch"])
             if "mfma_util_percent" in k:
                 roof["mfma_util_percent"] = round(k["mfma_util_percent"], 1)
@@ -229,12 +281,13 @@ def main():
                 return "marker"
             u = units[int(tiles[int(l[2])]["unit"])]
             if u["mode"] == 2:
-                return "side"        # rows below a sub-tile: left-looking update + solve (Winv)
+                return "trsm"        # rows below a panel / sub-tile: (left-looking update +) solve via Winv
             if u["mode"] == 1:
                 return "between"
-            # same-node updates by stream: chain = next diagonal sub-tile, side = rest of the
-            # near zone, bulk = trailing block columns
-            return {0: "next_diag", 3: "next_rest", 1: "trailing"}.get(int(l[6]), "update")
+            if bc_off[int(u["src_bcol0"])] == u["d_off"]:
+                return "inpanel"     # left-looking update of the next panel inside the block column
+            # block column c -> c+1 (chain stream) / its remainder (side stream) / c -> c+2.. (bulk)
+            return {0: "next", 3: "next_rest", 1: "trailing"}.get(int(l[6]), "update")
         with open(args.profile_out, "w") as fh:
             fh.write("idx kind level count tile gflop ms category\n")
             for i, (l, m) in enumerate(zip(Lh, ms)):
@@ -248,7 +301,25 @@ def main():
         if not args.no_check:
             ref = o.arena()
             check["max_relerr_L_vs_cpu"] = float(np.abs(L - ref).max() / np.abs(ref).max())
+            # the same system solved with the CPU oracle's factor, beside the GPU's
+            xc = o.solve(b)
+            rc_ = b - A @ xc
+            check["resid_2norm_rel_cpu_oracle"] = float(np.linalg.norm(rc_) / np.linalg.norm(b))
+            check["bwd_err_cpu_oracle"] = float(np.linalg.norm(rc_) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(xc)))
+            check["tolerance"] = ("pass iff bwd_err = ||r||/(||b|| + max|a_ij| ||x||) <= 1e-14 (reference "
+                                  "src/utils_mod.F90:462-467) and max|L - L_cpu|/max|L_cpu| <= 1e-12.  The plain "
+                                  "||r||/||b|| is ~1e-13 on this stand-in for BOTH factors: b = A*1 is a near-"
+                                  "cancelling row sum (||A|| ||x|| / ||b|| ~ 7e2), so eps * that ratio is the floor")
 
+    nlaunch = f.times()["launches"]
+    extra = []
+    if not args.no_extra_configs and not args.mm and not args.rb and args.scale == 1.0:
+        f.close()
+        del dval
+        torch.cuda.empty_cache()
+        for other in ("poisson3d_128", "serena_like"):
+            if other != args.config:
+                extra.append(run_extra_config(other))
     out = {
         "metric": "factorize GFLOP/s (fp64)", "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -257,13 +328,14 @@ def main():
         "config": {"workload": name, "stand_in_for": "SuiteSparse ND/nd24k" if "nd24k" in name else None,
                    "n": n, "nnz_lower": int(si["nnz_a"]), "nb": nb, "nnz_L": int(si["nnz_l"]),
                    "flops_sym": flops, "nnodes": int(si["nnodes"]), "ordering": si["ordering"] + ("/geometric-nd" if order is not None else ""),
-                   "parallelism": "1 GPU, level-batched stream DAG"},
+                   "parallelism": "1 GPU, level-batched stream DAG (chain / bulk / far streams, zone pipeline)"},
         "roofline": roof, "cpu_baseline": cpu,
         "detail": {"device_ms_per_step": round(float(np.mean(dev_ms)), 3), "analyse_s": round(t_analyse, 2),
                    "dropin_factor_s": round(t_h2d, 4), "L_d2h_s": round(t_d2h, 4),
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
-                   "launches": f.times()["launches"], "kernel_table": table, "check": check,
-                   "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin},
+                   "launches": nlaunch, "kernel_table": table, "check": check,
+                   "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin,
+                   "configs": extra},
     }
     print(json.dumps(out))
 

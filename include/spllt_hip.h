@@ -192,6 +192,10 @@ int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, do
 int64_t spllt_hip_program_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 /* per-launch device time (ms) of one profiled factorization; returns #launches */
 int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int capacity);
+/* the same for the real multi-stream program: every launch bracketed by two HIP events on
+ * the stream it runs on (behind its dependency waits), i.e. its duration beside whatever the
+ * other streams run at that moment */
+int spllt_hip_profile_in_program(void *fkeep, const double *val, int nnz, float *ms, int capacity);
 const char *spllt_hip_last_error(const void *fkeep);
 const char *spllt_hip_version(void);
 

@@ -272,12 +272,15 @@ class Factorization:
         raw = raw[:nbytes]
         return raw if name == "map_keep" else raw.view(np.int32)
 
-    def profile(self, val):
+    def profile(self, val, in_program=False):
+        """per-launch device time (ms) of one factorization: launches serialized on one
+        stream (kernels alone on the chip), or in_program=True: inside the real
+        multi-stream program (durations under contention)"""
         val = np.ascontiguousarray(val, dtype=np.float64)
         nl = len(self.program("launches"))
         ms = np.zeros(max(nl, 1), dtype=np.float32)
-        rc = self.lib.spllt_hip_profile(self.fkeep, _dp(val), self.nnz,
-                                        ms.ctypes.data_as(C.POINTER(C.c_float)), nl)
+        fn = self.lib.spllt_hip_profile_in_program if in_program else self.lib.spllt_hip_profile
+        rc = fn(self.fkeep, _dp(val), self.nnz, ms.ctypes.data_as(C.POINTER(C.c_float)), nl)
         if rc < 0:
             raise SplltError("spllt_hip_profile", rc, self.last_error())
         return ms[:rc]

@@ -747,13 +747,20 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   return -1;
 }
 
+static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int capacity, bool serial);
 int spllt_hip_profile(void* fkeep, const double* val, int nnz, float* ms, int capacity) {
+  return profile_impl(fkeep, val, nnz, ms, capacity, true);
+}
+int spllt_hip_profile_in_program(void* fkeep, const double* val, int nnz, float* ms, int capacity) {
+  return profile_impl(fkeep, val, nnz, ms, capacity, false);
+}
+static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int capacity, bool serial) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f || !f->S || !val) return SPLLT_ERROR_PARAMETER;
   if (!f->eng) f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
   if (!f->eng || f->eng->status()) return SPLLT_ERROR_HIP;
   std::vector<float> v;
-  int rc = f->eng->profile_launches(val, nnz, v);
+  int rc = f->eng->profile_launches(val, nnz, v, serial);
   if (rc) return rc;
   for (int i = 0; i < (int)v.size() && i < capacity; ++i) ms[i] = v[i];
   f->hostL_valid = false;

@@ -450,9 +450,15 @@ int Engine::solve(double* x_host, int nrhs, int job) {
   return 0;
 }
 
-int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms) {
+// Per-launch device time of one factorization from HIP events on the stream each launch
+// runs on.  serial = true: the whole program on one stream, launch after launch (the
+// kernels alone on the chip).  serial = false: the real multi-stream program; every
+// launch is bracketed by two events on ITS stream, recorded behind its dependency waits, so
+// the elapsed time is the launch's duration under the contention of whatever runs beside it.
+int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms, bool serial) {
   if (status_) return status_;
   if (nnz != S_->nnzA) return -10;
+  if (xchg_idx_ >= 0) return -98;   // single-GPU programs only
   const Symbolic& S = *S_;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipMemcpy(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice), "val H2D");
@@ -461,16 +467,29 @@ int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<fl
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
   launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
   size_t nl = prog_.launches.size();
-  std::vector<hipEvent_t> ev(nl + 1);
+  std::vector<hipEvent_t> ev(2 * nl);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e), "event create");
-  HIPCHK(hipEventRecord(ev[0], stream_), "event");
   for (size_t i = 0; i < nl; ++i) {
-    enqueue_launch(prog_.launches[i], true);
-    HIPCHK(hipEventRecord(ev[i + 1], stream_), "event");
+    const Launch& l = prog_.launches[i];
+    hipStream_t st = serial ? stream_ : streams_[l.stream];
+    if (!serial)
+      for (int w : l.wait)
+        if (w >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[w], 0), "stream wait");
+    HIPCHK(hipEventRecord(ev[2 * i], st), "event");
+    Launch bare = l;                       // waits already issued above; keep the record
+    for (int& w : bare.wait) w = -1;
+    bare.record = -1;
+    enqueue_launch(bare, serial);
+    HIPCHK(hipEventRecord(ev[2 * i + 1], st), "event");
+    if (!serial && l.record >= 0) HIPCHK(hipEventRecord(dag_events_[l.record], st), "event record");
+  }
+  if (!serial) {
+    if (prog_.final_event >= 0)
+      HIPCHK(hipStreamWaitEvent(stream_, dag_events_[prog_.final_event], 0), "final wait");
   }
   HIPCHK(hipStreamSynchronize(stream_), "sync");
   ms.assign(nl, 0.f);
-  for (size_t i = 0; i < nl; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  for (size_t i = 0; i < nl; ++i) hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]);
   for (auto& e : ev) hipEventDestroy(e);
   return 0;
 }

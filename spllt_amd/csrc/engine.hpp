@@ -82,7 +82,7 @@ class Engine {
   const Symbolic& symbolic() const { return *S_; }
   const FactorStats& stats() const { return stats_; }
   // per-launch device time of the last factorization (profiling mode)
-  int profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms);
+  int profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms, bool serial = true);
 
  private:
   int upload();
