@@ -121,6 +121,12 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * Bit 10 / bit 11 = force the zone pipeline on / off (inter-node updates at the end
  * of a level issued by destination block column so that the next level's panel chains
  * start beside them; default: on for latency-bound problems, see schedule.hpp).
+ * Bit 12 = deterministic engine: no atomic adds anywhere in the factorization.  The
+ * inter-node updates store their products in a scratch buffer and one workgroup per
+ * destination tile subtracts them in a fixed order (the reference's buffer + expand_buffer
+ * steps, serialised per destination like its OpenMP path, task_mod:1239-1241); two
+ * factorizations of the same values then give bit-identical factors.  Implies no zone
+ * pipeline and no early slices.
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
@@ -183,7 +189,8 @@ int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, do
 /* program export for tests: "launches" (int64 x 12 per launch: kind, level,
  * first, count, tile, flops, stream, record, wait0..wait3), "chains" (ChainUnit bytes),
  * "potrf" (PotrfUnit bytes), "units" (UpdUnit bytes), "tiles" (UpdTile bytes),
- * "relpos" (int32), "dinv_size" (int64), "chain_block" (int64); the substitution program:
+ * "relpos" (int32), "dinv_size" (int64), "chain_block" (int64), "gather_tiles" / "gather_items"
+ * (GatherTile / GatherItem bytes), "scratch_size" (int64); the substitution program:
  * "solve_units" (SolveUnit bytes), "solve_list" (int32), "solve_tiles" (UpdTile bytes),
  * "solve_fwd" / "solve_bwd" (int64 x 4 per launch: kind, level, first, count), "solve_split"
  * (int64 x 2: launches of fwd that belong to the own branches, launches of bwd that belong

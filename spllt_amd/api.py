@@ -29,6 +29,12 @@ UPD_UNIT_DTYPE = np.dtype([
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
 CHAIN_UNIT_DTYPE = np.dtype([("off", "<i8"), ("winv_off", "<i8"), ("ld", "<i4"), ("c0", "<i4"),
                              ("pn", "<i4"), ("cs", "<i4"), ("ce", "<i4"), ("gcol", "<i4")])
+GATHER_ITEM_DTYPE = np.dtype([("buf_off", "<i8"), ("relrow_off", "<i8"), ("gcol_off", "<i8"), ("ld", "<i4"),
+                              ("i0", "<i4"), ("i1", "<i4"), ("j0", "<i4"), ("j1", "<i4"),
+                              ("diag_shift", "<i4"), ("lower", "<i4"), ("pad_", "<i4")])
+GATHER_TILE_DTYPE = np.dtype([("d_off", "<i8"), ("d_ld", "<i4"), ("row0", "<i4"), ("col0", "<i4"),
+                              ("rows", "<i4"), ("cols", "<i4"), ("drow_base", "<i4"),
+                              ("dcol_base", "<i4"), ("first", "<i4"), ("count", "<i4"), ("pad_", "<i4")])
 # "launches": int64 x 12 per launch
 LAUNCH_COLS = ("kind", "level", "first", "count", "tile", "flops", "stream", "record",
                "wait0", "wait1", "wait2", "wait3")
@@ -152,8 +158,12 @@ class Factorization:
             return raw.view(POTRF_UNIT_DTYPE)
         if name == "chains":
             return raw.view(CHAIN_UNIT_DTYPE)
-        if name == "chain_block":
+        if name in ("chain_block", "scratch_size"):
             return int(raw.view(np.int64)[0])
+        if name == "gather_tiles":
+            return raw.view(GATHER_TILE_DTYPE)
+        if name == "gather_items":
+            return raw.view(GATHER_ITEM_DTYPE)
         if name == "relpos":
             return raw.view(np.int32)
         if name == "dinv_size":

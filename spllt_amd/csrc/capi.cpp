@@ -550,6 +550,7 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 256) f->eo.reserve_cus = 0;   // bit 8 set: no CU reservation for the chain
   if (flags & 1024) f->eo.zones = 1;        // bit 10 / 11: force the zone pipeline (and the atomic
   if (flags & 2048) f->eo.zones = 0;        // trailing updates that go with it) on / off
+  f->eo.deterministic = (flags & 4096) != 0;  // bit 12: no atomics (buffer + ordered gather)
   f->eo.side_on_chain = (flags & 512) == 0; // bit 9 set: rows below the sub-tiles on a side stream
   return 0;
 }
@@ -689,6 +690,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.lookahead = f->eo.lookahead;
     so.slice_between = f->eo.slice_between;
     so.side_on_chain = f->eo.side_on_chain;
+    so.deterministic = f->eo.deterministic;
     so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
     std::vector<int> owner;
     if (f->eo.nranks > 1) {
@@ -721,6 +723,9 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
   if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }
+  if (k == "gather_tiles") return raw(P->gather_tiles.data(), P->gather_tiles.size() * sizeof(GatherTile));
+  if (k == "gather_items") return raw(P->gather_items.data(), P->gather_items.size() * sizeof(GatherItem));
+  if (k == "scratch_size") { int64_t v = P->scratch_size; return raw(&v, sizeof v); }
   if (k == "dinv_size") { int64_t v = P->dinv_size; return raw(&v, sizeof v); }
   if (k.rfind("solve_", 0) == 0) {
     // the substitution program (partition-aware like the factor program)

@@ -60,6 +60,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.lookahead = opt_.lookahead;
   so.slice_between = opt_.slice_between;
   so.side_on_chain = opt_.side_on_chain;
+  so.deterministic = opt_.deterministic;
   {
     const bool lb = latency_bound(*S_, std::min(opt_.pw, kPanelMax));
     if (opt_.reserve_cus < 0) opt_.reserve_cus = lb ? 32 : 0;
@@ -178,7 +179,19 @@ int Engine::upload() {
   for (int b = 0; b < S.nbcol(); ++b) { off[b] = S.bcols[b].off; w[b] = S.bcols[b].width; }
   HIPCHK(dev_upload(&d_bc_off_, off), "upload bc_off");
   HIPCHK(dev_upload(&d_bc_w_, w), "upload bc_w");
-  HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
+  if (prog_.scratch_size > 0) {
+    HIPCHK(hipMalloc((void**)&d_scratch_, sizeof(double) * (size_t)prog_.scratch_size), "hipMalloc(scratch)");
+    // MODE_BUFFER units address the scratch relative to the arena pointer like every other unit
+    std::vector<UpdUnit> units(prog_.units);
+    const int64_t shift = d_scratch_ - d_L_;
+    for (UpdUnit& u : units)
+      if (u.mode == MODE_BUFFER) u.d_off += shift;
+    HIPCHK(dev_upload(&d_units_, units), "upload units");
+  } else {
+    HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
+  }
+  HIPCHK(dev_upload(&d_gtiles_, prog_.gather_tiles), "upload gather tiles");
+  HIPCHK(dev_upload(&d_gitems_, prog_.gather_items), "upload gather items");
   HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
   HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
@@ -193,7 +206,7 @@ Engine::~Engine() {
     if (st) hipStreamSynchronize(st);
   for (auto& e : dag_events_) if (e) hipEventDestroy(e);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
@@ -218,6 +231,8 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       launch_chain_panel(st, d_chain_ + l.first, l.count, l.tile, d_L_, d_dinv_, d_flag_);
     } else if (l.kind == L_WINV) {
       launch_winv(st, d_chain_ + l.first, l.count, d_L_, d_dinv_);
+    } else if (l.kind == L_GATHER) {
+      launch_gather(st, d_gtiles_ + l.first, l.count, d_gitems_, d_L_, d_scratch_, d_relpos_, d_rlist_);
     } else {
       // multi-stream program: chain / side launches run at raised wave priority
       const bool multi = !serial && opt_.lookahead;

@@ -22,6 +22,7 @@ struct EngineOptions {
   bool lookahead = true;   // multi-stream program (panel chain overlaps trailing updates)
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
   bool side_on_chain = true;   // see ScheduleOptions
+  bool deterministic = false;  // see ScheduleOptions
   bool poison_lds = false; // debug: poison the LDS of every CU before every launch
   int reserve_cus = -1;    // CUs the bulk / far streams are masked off (0: no mask; -1: 32 when the
                            // problem is latency-bound (schedule.hpp), else 0)
@@ -132,6 +133,9 @@ class Engine {
   UpdUnit* d_units_ = nullptr;
   UpdTile* d_tiles_ = nullptr;
   ChainUnit* d_chain_ = nullptr;
+  GatherTile* d_gtiles_ = nullptr;
+  GatherItem* d_gitems_ = nullptr;
+  double* d_scratch_ = nullptr;    // MODE_BUFFER products (deterministic engine)
   // device solve (built on first use)
   SolveProgram sprog_;
   bool solve_ready_ = false;

@@ -685,7 +685,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
       }
   } else {
     double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
-    const bool trsm = (u.mode == MODE_TRSM);
+    // TRSM writes X in place, BUFFER stores the product into the scratch block: plain stores
+    const bool trsm = (u.mode == MODE_TRSM) || (u.mode == MODE_BUFFER);
     const bool atomic = u.atomic != 0;
 #pragma unroll
     for (int a = 0; a < FMM; ++a) {
@@ -1132,6 +1133,52 @@ void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, i
 void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_winv, dim3((unsigned)count), dim3(kChainThreads), 0, st, units, L, dinv);
+}
+
+// ---------------------------------------------------------------------------
+// Deterministic assembly: dest tile -= sum over its items (in list order) of the buffered
+// update blocks.  a18 spllt_expand_buffer (kernels_mod:2010-2053) turned around: the
+// reference walks a buffer and adds into the destination (one task at a time per
+// destination, task_mod:1239-1241); here one workgroup owns a destination tile and walks
+// the buffers that hit it, so no two writers ever meet and the order of the adds is fixed.
+// HBM-bound: 8 B per buffered entry + 16 B per destination entry.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const GatherTile* __restrict__ tiles,
+                                                const GatherItem* __restrict__ items,
+                                                double* __restrict__ L,
+                                                const double* __restrict__ scratch,
+                                                const int* __restrict__ relpos,
+                                                const int* __restrict__ rlist) {
+  __shared__ double acc[64 * 65];
+  const GatherTile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 65; e += 256) acc[e] = 0.0;
+  __syncthreads();
+  for (int it = 0; it < t.count; ++it) {
+    const GatherItem g = items[t.first + it];
+    const int ni = g.i1 - g.i0, nj = g.j1 - g.j0;
+    const double* buf = scratch + g.buf_off;
+    for (int e = tid; e < ni * nj; e += 256) {
+      const int i = g.i0 + e / nj, j = g.j0 + e % nj;
+      if (g.lower && g.diag_shift + i < j) continue;
+      const int r = relpos[g.relrow_off + i] - t.drow_base - t.row0;
+      const int c = rlist[g.gcol_off + j] - t.dcol_base - t.col0;
+      acc[r * 65 + c] += buf[(int64_t)i * g.ld + j];   // (i, j) -> (r, c) is injective inside an item
+    }
+    __syncthreads();   // the next item may hit the same entries
+  }
+  double* D = L + t.d_off + (int64_t)t.row0 * t.d_ld + t.col0;
+  for (int e = tid; e < t.rows * t.cols; e += 256) {
+    const int r = e / t.cols, c = e % t.cols;
+    const double a = acc[r * 65 + c];
+    if (a != 0.0) D[(int64_t)r * t.d_ld + c] -= a;
+  }
+}
+
+void launch_gather(hipStream_t st, const GatherTile* tiles, int64_t count, const GatherItem* items,
+                   double* L, const double* scratch, const int* relpos, const int* rlist) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)count), dim3(256), 0, st, tiles, items, L, scratch, relpos, rlist);
 }
 
 // multi-GPU: the "not positive definite" flag travels with the exchange buffer.  Before the

@@ -19,6 +19,9 @@ void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, i
                         double* L, double* dinv, int* flag);
 // W part of Winv of the same units (side stream)
 void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv);
+// deterministic assembly of buffered inter-node update blocks (GatherTile / GatherItem)
+void launch_gather(hipStream_t st, const GatherTile* tiles, int64_t count, const GatherItem* items,
+                   double* L, const double* scratch, const int* relpos, const int* rlist);
 // multi-GPU: not-positive-definite flag <-> extra element of the exchange buffer
 void launch_flag_pack(hipStream_t st, const int* flag, double* slot);
 void launch_flag_unpack(hipStream_t st, const double* slot, int* flag);

@@ -286,6 +286,91 @@ struct Builder {
     return 2.0 * u.klen * (full - cut);
   }
 
+  // Deterministic inter-node updates: every SCATTER unit becomes a MODE_BUFFER unit whose
+  // product lands in the scratch buffer (one launch), then one L_GATHER launch subtracts the
+  // buffered blocks from their destination tiles, tile by tile, items in unit order.
+  void emit_buffered(int level, std::vector<UpdUnit>& us, double flops, Edge e) {
+    struct Key { int bd, rt, ct; };
+    std::vector<std::pair<Key, GatherItem>> items;
+    int64_t off = 0;
+    for (UpdUnit& u : us) {
+      const int bd = u.dinv_ld;                 // destination block column (between_templates)
+      const BlockCol& D = S.bcols[bd];
+      const int dcol_base = u.d_col0;           // pivot position of the block column's column 0
+      GatherItem g{};
+      g.buf_off = off;
+      g.relrow_off = u.relrow_off;
+      g.gcol_off = u.gcol_off;
+      g.ld = u.N;
+      g.diag_shift = u.src_r0 - u.src_c0;
+      g.lower = u.lower;
+      // runs of rows / columns that fall into the same 64-entry tile of the destination
+      std::vector<std::pair<int, int>> rruns, cruns;   // (first index, tile)
+      for (int i = 0; i < u.M; ++i) {
+        const int t = (P.relpos[u.relrow_off + i] - D.r0) / 64;
+        if (rruns.empty() || rruns.back().second != t) rruns.push_back({i, t});
+      }
+      for (int j = 0; j < u.N; ++j) {
+        const int t = (S.rlist[u.gcol_off + j] - dcol_base) / 64;
+        if (cruns.empty() || cruns.back().second != t) cruns.push_back({j, t});
+      }
+      for (size_t a = 0; a < rruns.size(); ++a) {
+        g.i0 = rruns[a].first;
+        g.i1 = a + 1 < rruns.size() ? rruns[a + 1].first : u.M;
+        for (size_t b = 0; b < cruns.size(); ++b) {
+          g.j0 = cruns[b].first;
+          g.j1 = b + 1 < cruns.size() ? cruns[b + 1].first : u.N;
+          if (g.lower && g.diag_shift + g.i1 - 1 < g.j0) continue;   // entirely above the diagonal
+          items.push_back({Key{bd, rruns[a].second, cruns[b].second}, g});
+        }
+      }
+      // the unit itself: product stored at scratch[off ...], M x N row-major
+      u.mode = MODE_BUFFER;
+      u.d_off = off;
+      u.d_ld = u.N;
+      u.d_row0 = 0;
+      u.d_col0 = 0;
+      off += (int64_t)u.M * u.N;
+    }
+    P.scratch_size = std::max(P.scratch_size, off);
+    std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) {
+      if (x.first.bd != y.first.bd) return x.first.bd < y.first.bd;
+      if (x.first.rt != y.first.rt) return x.first.rt < y.first.rt;
+      return x.first.ct < y.first.ct;
+    });
+    Launch G;
+    G.kind = L_GATHER;
+    G.level = level;
+    G.first = (int64_t)P.gather_tiles.size();
+    G.tile = 64;
+    G.flops = 0;
+    G.stream = e.stream;
+    for (size_t i = 0; i < items.size();) {
+      const Key k = items[i].first;
+      const BlockCol& D = S.bcols[k.bd];
+      GatherTile t{};
+      t.d_off = D.off;
+      t.d_ld = D.width;
+      t.row0 = k.rt * 64;
+      t.col0 = k.ct * 64;
+      t.rows = std::min(64, D.nrow - t.row0);
+      t.cols = std::min(64, D.width - t.col0);
+      t.drow_base = D.r0;
+      t.dcol_base = S.sptr[D.node] + D.r0;
+      t.first = (int)P.gather_items.size();
+      for (; i < items.size() && items[i].first.bd == k.bd && items[i].first.rt == k.rt &&
+             items[i].first.ct == k.ct; ++i)
+        P.gather_items.push_back(items[i].second);
+      t.count = (int)P.gather_items.size() - t.first;
+      P.gather_tiles.push_back(t);
+    }
+    G.count = (int64_t)P.gather_tiles.size() - G.first;
+    Edge eg = e;
+    eg.record = -1;
+    emit_gemm(level, us, flops, true, eg);   // (a marker when there is nothing to do)
+    P.launches.push_back(G);                 // same stream, in order behind the products
+  }
+
   void run() {
     P.pw = pw;
     const int cb = std::max(pw, (std::max(opt.cb, pw) / pw) * pw);   // multiple of the panel width
@@ -309,6 +394,7 @@ struct Builder {
 
     const bool la = opt.lookahead;
     const bool soc = opt.side_on_chain;
+    const bool det = opt.deterministic;
     auto edge = [&](int stream) {
       Edge e;
       e.stream = (!la || (soc && stream == ST_SIDE)) ? ST_CHAIN : stream;
@@ -632,7 +718,7 @@ struct Builder {
             // (4b) early inter-node slices: block columns 0..c are final, so the part
             // of update_between that reads them can run beside the remaining panel
             // chains of the level (far stream) instead of after the last one
-            if (la && opt.slice_between && c + 1 < maxnc) {
+            if (la && opt.slice_between && !det && c + 1 < maxnc) {
               std::vector<UpdUnit> sl;
               double fs_ = collect_between(nodes, tmpl, emitted, c + 1, false, sl);
               if (!sl.empty()) {
@@ -656,13 +742,27 @@ struct Builder {
       P.flops_between += fl;
       zone_events.clear();
       zoned = false;
-      if (!la) {
+      if (det) {
+        // deterministic engine: products into the scratch buffer, then an ordered gather per
+        // destination tile (no atomics anywhere)
+        Edge e = edge(ST_FAR);
+        if (la) {
+          e.wait0 = evD_last;
+          e.wait1 = ev_level;
+        }
+        emit_buffered(lev, rest, fl, e);
+        if (la) {
+          ev_level = P.nevents++;
+          P.launches.back().record = ev_level;
+          zone_events.push_back({0, ev_level});   // every step of the next level waits for all of it
+        }
+      } else if (!la) {
         emit_gemm(lev, rest, fl);
       } else {
         // far stream, sorted by destination zone (see above); the event of the last zone
         // covers the whole level
         static const int zones_env = (int)env_int("SPLLT_ZONES", -1);
-        const bool use_zones = zones_env >= 0 ? zones_env != 0 : opt.zones;
+        const bool use_zones = !det && (zones_env >= 0 ? zones_env != 0 : opt.zones);
         auto zone_of = [&](const UpdUnit& u) {
           const int a = S.bcols[u.dinv_ld].node;
           if (!use_zones) return 0;   // one zone: every step of the next level waits for all of it

@@ -24,7 +24,12 @@ namespace spx {
 
 constexpr int kPanelMax = 64;  // widest diagonal panel the POTRF kernel accepts
 
-enum UnitMode : int { MODE_DIRECT = 0, MODE_SCATTER = 1, MODE_TRSM = 2 };
+enum UnitMode : int { MODE_DIRECT = 0, MODE_SCATTER = 1, MODE_TRSM = 2, MODE_BUFFER = 3 };
+// MODE_BUFFER (deterministic engine): the product of an inter-node update unit is STORED, as a
+// dense M x N row-major block, in a scratch buffer (d_off = its offset there, d_ld = N); a
+// k_gather launch then subtracts the buffered blocks from their destination tiles in a fixed
+// order -- the reference's own two steps, update_between into a buffer + expand_buffer
+// (kernels_mod:2108-2237, :2010-2053), made destination-centric instead of atomic.
 
 // One batched-GEMM work unit:   C[rowmap(i)][colmap(j)] (-)= sum_seg A_seg[i][:] . B_seg[j][:]
 // A rows are node-local rows [src_r0, src_r0+M) of the source supernode, B rows
@@ -85,7 +90,32 @@ struct ChainUnit {
 };
 static_assert(sizeof(ChainUnit) == 40, "ChainUnit layout (mirrored in spllt_amd/api.py)");
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5 };
+// Deterministic assembly (k_gather): one workgroup per destination tile (<= 64 x 64 entries of
+// a block column) walks its items in order; an item is the part of one buffered update block
+// (MODE_BUFFER unit) that lands in the tile.
+struct GatherItem {
+  int64_t buf_off;     // scratch offset of the unit's block (entry (0, 0))
+  int64_t relrow_off;  // relpos[] offset of the unit's row 0
+  int64_t gcol_off;    // rlist[] offset of the unit's column 0
+  int ld;              // row width of the buffered block (= unit N)
+  int i0, i1, j0, j1;  // rows / columns of the block that land in the tile
+  int diag_shift;      // src_r0 - src_c0 of the unit: only entries with diag_shift + i >= j count
+  int lower, pad_;
+};
+static_assert(sizeof(GatherItem) == 56, "GatherItem layout (mirrored in spllt_amd/api.py)");
+struct GatherTile {
+  int64_t d_off;       // arena offset of the destination block column
+  int d_ld;            // its row width
+  int row0, col0;      // tile origin (stored row / column of the block column)
+  int rows, cols;      // tile extent (<= 64 each)
+  int drow_base;       // node-local row of the block column's stored row 0 (relpos is node-local)
+  int dcol_base;       // pivot position of the block column's column 0 (rlist holds pivot positions)
+  int first, count;    // range in gather_items
+  int pad_;
+};
+static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
+
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5, L_GATHER = 6 };
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
 // the side stream (rows below the sub-tiles: off the critical path by one step), the bulk and
@@ -120,6 +150,9 @@ struct Program {
   int cb = 64;  // chain block: edge of the diagonal sub-tiles the chain kernels walk
   std::vector<PotrfUnit> potrf_units;  // L_POTRF (operator twins only: inverse of given factors)
   std::vector<ChainUnit> chain_units;  // L_CHAIN, L_WINV
+  std::vector<GatherItem> gather_items;
+  std::vector<GatherTile> gather_tiles;  // L_GATHER
+  int64_t scratch_size = 0;     // doubles of the MODE_BUFFER scratch (largest launch)
   std::vector<UpdUnit> units;
   std::vector<UpdTile> tiles;
   std::vector<Launch> launches;
@@ -148,6 +181,8 @@ struct ScheduleOptions {
                               // sorted by destination block column, one event per zone, so that
                               // the next level's chains start beside them; the trailing updates
                               // of a level that starts this way subtract with atomics
+  bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
+                              // (MODE_BUFFER / k_gather); implies no zones, no early slices
   bool side_on_chain = true;  // the rows below the sub-tiles and the near-zone updates stay on the
                               // chain stream: more kernels in the chain, no cross-stream hand-offs
                               // (each costs 10-20 us) inside it

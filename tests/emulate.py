@@ -27,6 +27,7 @@ def emulate_program(f, val, exchange=None, partitioned=False):
     rlist = f.sym("rlist")
     bc_off, bc_w = f.sym("bcol_off"), f.sym("bcol_width")
     dinv = np.zeros(max(1, f.program("dinv_size")))
+    scratch = np.zeros(max(1, f.program("scratch_size")))   # MODE_BUFFER products (deterministic engine)
 
     def seg_rows(u, sg, r0, cnt, from_b):
         """rows [r0, r0+cnt) x K-window of segment sg as a dense (cnt x klen) array"""
@@ -86,6 +87,28 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                     keep = np.tril(np.ones((ce - c0 - pn,) * 2, dtype=bool))
                     arena[ti[keep]] -= (X @ X.T)[keep]
             continue
+        if kind == 6:  # ordered gather of buffered update blocks into destination tiles (k_gather)
+            gt, gi = f.program("gather_tiles"), f.program("gather_items")
+            for t in gt[first:first + count]:
+                acc = np.zeros((64, 64))
+                for g in gi[int(t["first"]):int(t["first"]) + int(t["count"])]:
+                    ii = np.arange(int(g["i0"]), int(g["i1"]))
+                    jj = np.arange(int(g["j0"]), int(g["j1"]))
+                    blk = scratch[int(g["buf_off"]) + ii[:, None] * int(g["ld"]) + jj[None, :]]
+                    keep = np.ones(blk.shape, dtype=bool)
+                    if g["lower"]:
+                        keep = (int(g["diag_shift"]) + ii[:, None]) >= jj[None, :]
+                    r = relpos[int(g["relrow_off"]) + ii] - int(t["drow_base"]) - int(t["row0"])
+                    c = rlist[int(g["gcol_off"]) + jj] - int(t["dcol_base"]) - int(t["col0"])
+                    assert r.min() >= 0 and r.max() < t["rows"] and c.min() >= 0 and c.max() < t["cols"]
+                    sub = acc[np.ix_(r, c)]
+                    sub[keep] += blk[keep]
+                    acc[np.ix_(r, c)] = sub
+                rows, cols = int(t["rows"]), int(t["cols"])
+                idx = (int(t["d_off"]) + (int(t["row0"]) + np.arange(rows))[:, None] * int(t["d_ld"]) +
+                       int(t["col0"]) + np.arange(cols)[None, :])
+                arena[idx] -= acc[:rows, :cols]
+            continue
         if kind == 5:  # W part of Winv (k_winv): -inv(L_pp) L[c0:c0+pn, cs:c0]
             for q in f.program("chains")[first:first + count]:
                 ld, off = int(q["ld"]), int(q["off"])
@@ -142,6 +165,9 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                        int(u["d_col0"]) + jj)
                 if u["mode"] == MODE_TRSM:
                     arena[idx] = P
+                elif u["mode"] == 3:   # MODE_BUFFER: the product goes to the scratch block
+                    sidx = int(u["d_off"]) + ii * int(u["d_ld"]) + jj
+                    scratch[sidx] = P
                 else:
                     arena[idx[keep]] -= P[keep]
     return arena

@@ -461,6 +461,36 @@ def test_partitioned_not_posdef_is_reported_on_every_rank():
         f.close()
 
 
+@pytest.mark.parametrize("gen,nb", [(lambda: matgen.nd_like((14, 13, 12), 2), 64),
+                                    (lambda: matgen.poisson3d(22), 48),
+                                    (lambda: matgen.fe27((8, 7, 7), 3), 256)])
+def test_deterministic_engine_is_bit_reproducible(gen, nb):
+    """Engine flag 4096: no atomic adds (inter-node updates through a buffer + ordered
+    gather, k_gather).  Two factorizations of the same values must give bit-identical
+    factors (np.array_equal) -- the reference's OpenMP path serialises the updates of a
+    destination (task_mod:1239-1241) and has this property; the default engine (fp64
+    atomics in the scatter epilogue) only reproduces L to rounding.  Also checked against
+    the oracle, and re-factorization with other values in between."""
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=16, engine_flags=4096)
+    assert (f.program("launches")[:, 0] == 6).any()
+    L1 = f.factor(val).wait().get_factor()
+    f.factor(val * 3.0).wait()
+    L2 = f.factor(val).wait().get_factor()
+    assert np.array_equal(L1, L2)
+    g, _ = make_case(A, nb=nb, nemin=16, engine_flags=4096)      # a second engine instance
+    assert np.array_equal(g.factor(val).wait().get_factor(), L1)
+    o, rc = oracle_factor(f, val, variant="mkl" if f.n > 4000 else "plain", nthreads=4)
+    assert rc == 0
+    mask = lower_mask(f)
+    assert rel_err(L1, o.arena(), mask) <= TOL_L
+    assert np.all(L1[~mask] == 0.0)
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
+    f.close()
+    g.close()
+
+
 def test_golden_vectors_gpu():
     """tests/golden/dense_chol_*.npz (dense LAPACK factors for a fixed order):
     the HIP path must reproduce them to 1e-12 and solve to x = 1."""
@@ -480,7 +510,7 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("flags", [2, 64, 66, 256, 512, 576, 1024, 2048])
+@pytest.mark.parametrize("flags", [2, 64, 66, 256, 512, 576, 1024, 2048, 4096, 4098])
 @pytest.mark.parametrize("cb", [None, 32, 96, 160])
 def test_engine_variants_match_oracle(flags, cb):
     """single-stream program (2), inter-node updates only at the end of a level (64), both
@@ -497,7 +527,7 @@ def test_engine_variants_match_oracle(flags, cb):
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
-@pytest.mark.parametrize("flags", [128, 130, 192, 640])
+@pytest.mark.parametrize("flags", [128, 130, 192, 640, 4224])
 @pytest.mark.parametrize("nb,pw,cb", [(48, 5, None), (100, 40, 100), (130, 48, 96), (33, 12, 24),
                                       (256, 64, 256), (200, 24, 72)])
 def test_no_kernel_reads_uninitialised_lds(flags, nb, pw, cb):

@@ -148,10 +148,17 @@ def _access_sets(f):
                 R.append((b, c0, c0 + pn, cs, c0))
                 R.append(("wi", b, c0 // pw))
                 W.append(("ww", b, c0 // pw))      # W part of Winv
+        elif kind == 6:
+            gt = f.program("gather_tiles")
+            R.append(("scratch", 0, 0))
+            for t in gt[first:first + count]:
+                b = bcol_of(t["d_off"])
+                r0, c0 = int(t["row0"]), int(t["col0"])
+                W.append((b, r0, r0 + int(t["rows"]), c0, c0 + int(t["cols"])))
         elif kind == 1:
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 u = units[uid]
-                db = bcol_of(u["d_off"])
+                db = bcol_of(u["d_off"]) if u["mode"] != 3 else -1
                 M, N = int(u["M"]), int(u["N"])
                 for sg in range(int(u["nseg"])):
                     sb = int(u["src_bcol0"]) + sg
@@ -164,6 +171,9 @@ def _access_sets(f):
                         rb = int(u["src_c0"]) - sh
                         R.append((sb, rb, rb + N, k0, k1))
                 dr0, dc0 = int(u["d_row0"]), int(u["d_col0"])
+                if u["mode"] == 3:
+                    W.append(("scratch", 0, 0))
+                    continue
                 if u["mode"] == 2:
                     R.append(("wi", db, dc0 // pw))
                     if int(u["klen"]) > N:
@@ -238,7 +248,7 @@ def dag_violations(f):
                                         (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8),   # many block columns per node
                                         (lambda: matgen.nd_like((9, 8, 8), 2), 100, 8)])
 @pytest.mark.parametrize("cb", [0, 16, 40])
-@pytest.mark.parametrize("flags", [0, 64, 512, 576, 1024, 2048, 2560])
+@pytest.mark.parametrize("flags", [0, 64, 512, 576, 1024, 2048, 2560, 4096, 4608])
 def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
     """Multi-stream program (chain, side, bulk, far, wide): any two launches that touch the
     same entries (write/write, read/write, atomic/plain) must be ordered by stream order or
@@ -253,6 +263,10 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert ((launches[:, 6] == 3).any()) == bool(flags & 512), "side-stream launches only in that variant"
     assert (launches[:, 0] == 4).any()
+    assert ((launches[:, 0] == 6).any()) == bool(flags & 4096), "gather launches only in the deterministic engine"
+    if flags & 4096:
+        units = f.program("units")
+        assert not (units["mode"] == 1).any() and not units["atomic"].any(), "no atomic unit at all"
     # the final event covers everything: last launch of each stream precedes it
     fin = max(rec_at.values())
     for st, i in last_in_stream.items():
@@ -270,7 +284,7 @@ def test_single_stream_program_has_no_events():
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
-@pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048])
+@pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048, 4096, 4098])
 @pytest.mark.parametrize("cb", [0, 16, 32])
 def test_program_variants_agree(flags, cb, monkeypatch):
     """multi-stream / single-stream programs, with and without early inter-node slices, rows
