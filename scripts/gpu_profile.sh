@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round profile of ONE configuration on the GPU box (from the repository root):
+#   bash scripts/gpu_profile.sh <tag> "<bench.py args>"
+# 1. rocprofv3 --kernel-trace --stats of the default bench command
+# 2. separate rocprofv3 --pmc passes (kernel-trace only, as the pool requires): FETCH_SIZE,
+#    WRITE_SIZE (HBM traffic), SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe use)
+# Outputs under gpurun_out/prof_<tag>/; scripts/profile_summary.py turns them into profiles/.
+set -o pipefail
+TAG=$1; ARGS=$2
+OUT=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/prof_$TAG
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+B="--steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extra-configs $ARGS"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py $B > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+for C in FETCH_SIZE WRITE_SIZE MFMA_BUSY; do
+  case $C in
+    MFMA_BUSY) CTRS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE";;
+    *) CTRS=$C;;
+  esac
+  timeout -k 10 500 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $REPO/bench.py $B > $OUT/pmc_$C.log 2>&1
+  echo "$C rc=$?"
+done
+# keep what the summary needs, drop the rest (64 MiB merge limit)
+find $OUT -name "*.csv" ! -name "*kernel_trace.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
+python3 $REPO/scripts/profile_summary.py $TAG $OUT "$ARGS" > $OUT/summary.log 2>&1; echo "summary rc=$?"; tail -3 $OUT/summary.log
+find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
+ls -la $OUT

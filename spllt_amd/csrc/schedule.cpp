@@ -81,7 +81,11 @@ struct Builder {
     static const int64_t small_max = env_int("SPLLT_TILE_SMALL", 4096);
     static const int64_t tiny_max = env_int("SPLLT_TILE_TINY", 2048);
     const bool small_launch = n128 > 0 && n128 < small_max;
-    const bool tiny_launch = n64 > 0 && n64 <= tiny_max;
+    // 32-tiles are for latency: throughput launches (bulk / far streams: trailing updates,
+    // zones of the inter-node updates) keep 64-tiles unless they cannot even fill the chip once
+    static const int64_t tiny_bulk = env_int("SPLLT_TILE_TINY_BULK", 512);
+    const bool throughput = e.stream == ST_BULK || e.stream == ST_FAR;
+    const bool tiny_launch = n64 > 0 && n64 <= (throughput ? tiny_bulk : tiny_max);
     for (auto& u : us) {
       int uid = (int)P.units.size();
       u.a_w = S.bcols[u.src_bcol0].width;

@@ -527,10 +527,10 @@ def test_engine_variants_match_oracle(flags, cb):
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
-@pytest.mark.parametrize("flags", [128, 130, 192, 640, 4224])
-@pytest.mark.parametrize("nb,pw,cb", [(48, 5, None), (100, 40, 100), (130, 48, 96), (33, 12, 24),
-                                      (256, 64, 256), (200, 24, 72)])
-def test_no_kernel_reads_uninitialised_lds(flags, nb, pw, cb):
+@pytest.mark.parametrize("nb,pw,cb,flags", [(48, 5, None, 128), (100, 40, 100, 130), (130, 48, 96, 192),
+                                            (33, 12, 24, 640), (256, 64, 256, 128), (200, 24, 72, 4224),
+                                            (130, 48, None, 4224), (256, 64, None, 640)])
+def test_no_kernel_reads_uninitialised_lds(nb, pw, cb, flags):
     """Engine flag 128: before EVERY kernel launch of the factorization a poison kernel
     fills the whole LDS of every CU with signalling-NaN bit patterns.  A kernel that reads
     LDS it has not written (zero padding assumed, columns past a ragged panel, ...) then
