@@ -29,6 +29,16 @@
 
 #include "kernels.hpp"
 
+// shape of the 128-tile update kernel (scripts/update_bench.hip builds variants with
+// -DUPD128_BK / -DUPD128_WM / -DUPD128_WN)
+#ifndef UPD128_BK
+#define UPD128_BK 16
+#endif
+#ifndef UPD128_WM
+#define UPD128_WM 4
+#define UPD128_WN 2
+#endif
+
 namespace spx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1235,7 +1245,7 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev != attr_dev) {
-      (void)hipFuncSetAttribute((const void*)k_update<128, 16, 4, 2>,
+      (void)hipFuncSetAttribute((const void*)k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
       (void)hipFuncSetAttribute((const void*)k_update<64, 16, 2, 2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
@@ -1243,7 +1253,8 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
     }
   }
   if (tile == 128)
-    hipLaunchKernelGGL((k_update<128, 16, 4, 2>), dim3((unsigned)count), dim3(512), pad, st, tiles,
+    hipLaunchKernelGGL((k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>), dim3((unsigned)count),
+                       dim3(64 * UPD128_WM * UPD128_WN), pad, st, tiles,
                        units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
   else if (tile == 64)
     hipLaunchKernelGGL((k_update<64, 16, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
