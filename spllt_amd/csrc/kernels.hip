@@ -356,6 +356,23 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
 // LDS: PotrfShared, whose T (dead after step 1) and the dynamic LDS behind it hold
 // U = X (up to ce-c0-pn rows, zero padded to a multiple of 16).
 // ---------------------------------------------------------------------------
+// The chain step of a panel that is its whole sub-tile (chain block = panel width, the default):
+// nothing but the POTRF and its inverse.  256 threads and static LDS: two workgroups per CU
+// instead of the one that the 768-thread kernel below gets -- the leaf levels of a large
+// problem are thousands of such panels and run at the rate the chip retires these workgroups
+// (k_chain_panel there: 171 of 278 ms of kernel time on Poisson3D 128^3).
+__global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict__ units,
+                                                     double* __restrict__ L,
+                                                     double* __restrict__ dinv,
+                                                     int* __restrict__ flag) {
+  __shared__ PotrfShared sh;
+  __builtin_amdgcn_s_setprio(3);
+  const ChainUnit u = units[blockIdx.x];
+  const int cq = u.c0 - u.cs;
+  potrf64_body(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, cq + u.pn,
+               u.gcol, 0, flag);
+}
+
 constexpr int kChainThreads = 768;    // 12 waves: a single wave issues an fp64 MFMA only every
                                       // ~150 cycles; three per SIMD fit the register budget of the POTRF part (158 VGPRs)
 
@@ -1128,6 +1145,10 @@ static unsigned chain_lds_bytes(int max_rows_below) {
 void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, int max_rows_below,
                         double* L, double* dinv, int* flag) {
   if (count <= 0) return;
+  if (max_rows_below <= 0) {   // every panel of the launch is its whole sub-tile
+    hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+    return;
+  }
   thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
