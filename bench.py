@@ -110,6 +110,30 @@ def roofline_from_profile(f, val):
     return roof, table, ms
 
 
+PROFILE_DIRS = {"nd24k_like": "nd24k", "poisson3d_128": "p3d128", "serena_like": "serena"}
+
+
+def attach_pmc(roof, workload):
+    """HBM traffic and matrix-pipe utilisation of the dominant kernel come from separate
+    rocprofv3 --pmc passes (scripts/gpu_profile.sh: FETCH_SIZE / WRITE_SIZE / MFMA busy cannot
+    be read from inside this process); the committed per-launch summary of the SAME command is
+    quoted when it was taken on this very workload."""
+    try:
+        path = os.path.join(ROOT, "profiles", "r02", PROFILE_DIRS[workload], "summary.json")
+        with open(path) as fh:
+            pmc = json.load(fh)
+        k = pmc.get("kernels", {}).get(roof["kernel"])
+        if pmc.get("workload") == workload and k:
+            roof["traffic"] = round(k["hbm_bytes_per_launch"])
+            roof["traffic_unit"] = ("bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
+                                    f"profiles/r02/{PROFILE_DIRS[workload]}/summary.json)")
+            roof["algorithmic_bytes_per_launch"] = round(k["algorithmic_bytes_per_launch"])
+            if k.get("mfma_util_percent") is not None:
+                roof["mfma_util_percent"] = round(k["mfma_util_percent"], 1)
+    except (OSError, ValueError, KeyError):
+        pass
+
+
 def run_extra_config(cfg_name, steps=2):
     """One of the other BASELINE.json configurations with the same engine, reported under
     detail.configs (never as `value`): resident GFLOP/s, accuracy, dominant-kernel rate."""
@@ -252,23 +276,7 @@ def main():
                  "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))}
 
     roof, table, ms = roofline_from_profile(f, val)
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc
-    # passes (scripts/gpu_pmc.sh; FETCH_SIZE/WRITE_SIZE cannot be read from
-    # inside this process); the committed summary is quoted when it was taken
-    # on this very workload.
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")) as fh:
-            pmc = json.load(fh)
-        k = pmc.get("kernels", {}).get(roof["kernel"])
-        if pmc.get("workload") == name and k:
-            roof["traffic"] = round(k["hbm_bytes_per_launch"])
-            roof["traffic_unit"] = ("bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                                    "profiles/r02/pmc_summary.json)")
-            roof["algorithmic_bytes_per_launch"] = round(k["algorithmic_bytes_per_launch"])
-            if "mfma_util_percent" in k:
-                roof["mfma_util_percent"] = round(k["mfma_util_percent"], 1)
-    except (OSError, ValueError, KeyError):
-        pass
+    attach_pmc(roof, name)
     if args.profile_out:
         Lh = f.program("launches")
         units, tiles = f.program("units"), f.program("tiles")

@@ -5,14 +5,15 @@
  * include, link or call this; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py do, and only as the checker / reported baseline.
  *
- * Parity status: pinned by (i) the reference's only known-answer case for this
- * path, example/C/simple.c (3x3 tridiagonal, x = (1.5, 2, 1.5)), (ii) the
- * reference's residual bar ||Ax-b||/||b|| <= 1e-14 (drivers/spllt_omp_bench.F90:389)
- * and (iii) agreement with an independent dense LAPACK Cholesky of P A P^T
- * (uniqueness of the Cholesky factor).  The reference Fortran itself is NOT
- * built here: every module of its factor path uses SPRAL's
- * `spral_ssids_inform` module (src/spllt_data_mod.F90:13), SPRAL is not in this
- * image, and writing a stand-in for it is not permitted -> no oracle/_ref.
+ * Parity status: PARITY UNPINNED.  The reference holds no golden output for this path
+ * (example/C/simple.c has inputs only; tests/golden/kat_simple_c.json is the closed-form
+ * answer of that 3x3 case, typed here) and its Fortran cannot be built in this image: every
+ * module of its factor path uses SPRAL's `spral_ssids_inform` module
+ * (src/spllt_data_mod.F90:13), SPRAL is absent, and writing a stand-in for it is not
+ * permitted -> no oracle/_ref.  What checks this restatement instead: (i) that 3x3 case,
+ * (ii) the reference's residual bar ||r||/(||b|| + max|a| ||x||) <= 1e-14
+ * (src/utils_mod.F90:462-467) and (iii) agreement with an independent dense LAPACK Cholesky
+ * of P A P^T (uniqueness of the Cholesky factor).
  *
  * Each function cites the reference routine (file:line under /root/reference)
  * whose behaviour it restates.  All indices are 0-based here.
