@@ -103,7 +103,7 @@ def test_owner_assignment_is_balanced_and_covers_subtrees():
         assert (owner == -1).sum() < 0.25 * nn
 
 
-def _gpu_worker(rank, world, port, ret):
+def _gpu_worker(rank, world, port, ret, stream_ordered=False):
     """one process per rank, every rank on device 0, reduction over gloo: the production
     DistributedFactorization (factor with the exchange on the engine's stream, then the
     three-phase solve) end to end"""
@@ -113,6 +113,10 @@ def _gpu_worker(rank, world, port, ret):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if stream_ordered:
+        # the RCCL code path (collective enqueued under the engine's stream wrapped as a torch
+        # ExternalStream, no host synchronisation of ours between the phases), driven through gloo
+        os.environ["SPLLT_FORCE_STREAM_ORDERED"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -138,13 +142,14 @@ def _gpu_worker(rank, world, port, ret):
 
 
 @pytest.mark.gpu
-def test_distributed_factorization_two_processes_one_gpu():
+@pytest.mark.parametrize("stream_ordered", [False, True])
+def test_distributed_factorization_two_processes_one_gpu(stream_ordered):
     import torch.multiprocessing as mp
     world = 2
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + (os.getpid() % 2000) + (7 if stream_ordered else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_gpu_worker, args=(world, port, ret, stream_ordered), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         bwd, err, phases = ret[rank]
