@@ -1,21 +1,26 @@
 // Hand-written CDNA4 (gfx950) kernels of the factorize hot path.
 //
 //   k_scatter_val   a8  spllt_init_node   (reference src/spllt_kernels_mod.F90:2301-2364)
-//   k_potrf_panel   a11 spllt_factor_diag_block (:1168-1189) on <=64-wide panels,
-//                   also emits the inverse of the factored panel for the TRSM
-//   k_update<T>     a12 spllt_solve_block (:1217) as X = A * inv(L_pp)^T,
+//   k_chain_potrf   a11 spllt_factor_diag_block (:1168-1189) on one <=64-wide panel per
+//                   workgroup, also emits the inverse of the factored panel (the default
+//                   chain step); k_potrf_panel: the same body for the operator twins
+//   k_chain_panel   the chain step when the chain block is wider than a panel: POTRF of the
+//                   panel, the rows of its diagonal sub-tile below it and their update of
+//                   the rest of the sub-tile in ONE workgroup
+//   k_winv          W part of Winv = [ -inv(L_pp) L[p, cs:c0] | inv(L_pp) ], which turns the
+//                   left-looking update + TRSM of a row block into one k_update product
+//   k_update<T>     a12 spllt_solve_block (:1217) as X = [X_left | A] * Winv^T,
 //                   a13 spllt_update_block (:1261-1292),
 //                   a16+a18 spllt_update_between + spllt_expand_buffer
-//                   (:2108-2237, :2010-2053) with the scatter fused into the
-//                   GEMM epilogue -- one fp64-MFMA kernel, three epilogues.
+//                   (:2108-2237, :2010-2053) with the scatter fused into the GEMM
+//                   epilogue, or (deterministic engine) stored into a scratch block
+//                   -- one fp64-MFMA kernel, four epilogues.
+//   k_gather        a18 turned destination-centric: ordered assembly of the buffered update
+//                   blocks (deterministic engine, no atomics)
 //   k_scatter_block a26 spllt_scatter_block (:1122-1160) extend-add
 //   k_solve_diag / k_solve_strip   forward / backward substitution on the device-resident
 //                   factor (reference src/spllt_solve_mod.F90), up to 4 right-hand sides
-//   k_chain_panel   one step of the panel chain of a diagonal sub-tile in ONE workgroup:
-//                   POTRF of the panel's diagonal block, the rows of the sub-tile below it,
-//                   their update of the rest of the sub-tile, and the matrix Winv that turns
-//                   the left-looking update + TRSM of every row below the sub-tile into one
-//                   k_update (TRSM mode) product
+//   k_flag_pack / k_flag_unpack   multi-GPU: not-positive-definite indicator <-> exchange buffer
 //   k_poison_lds    debug: fills the LDS of every CU with signalling-NaN patterns
 //
 // Storage convention: every block column of L is a
