@@ -115,9 +115,9 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * kernel launch (a kernel that reads LDS it has not written then computes NaNs),
  * bit 8 = no CU reservation (default: the streams that carry the trailing updates
  * are masked off 16 CUs, which the latency-critical panel-chain kernels then find
- * free), bit 9 = the rows below the diagonal sub-tiles and the near-zone updates go
- * to a side stream one step behind the chain instead of staying in it (fewer kernels
- * in the chain, but every cross-stream hand-off costs 10-20 us: measured slower).
+ * free).  (Bit 9 selected a variant that ran the rows below the diagonal sub-tiles on a
+ * side stream one step behind the chain: slower - every cross-stream hand-off costs
+ * 10-20 us - and removed; the bit is ignored.)
  * Bit 10 / bit 11 = force the zone pipeline on / off (inter-node updates at the end
  * of a level issued by destination block column so that the next level's panel chains
  * start beside them; default: on for latency-bound problems, see schedule.hpp).

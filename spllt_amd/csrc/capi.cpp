@@ -551,7 +551,6 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 1024) f->eo.zones = 1;        // bit 10 / 11: force the zone pipeline (and the atomic
   if (flags & 2048) f->eo.zones = 0;        // trailing updates that go with it) on / off
   f->eo.deterministic = (flags & 4096) != 0;  // bit 12: no atomics (buffer + ordered gather)
-  f->eo.side_on_chain = (flags & 512) == 0; // bit 9 set: rows below the sub-tiles on a side stream
   return 0;
 }
 
@@ -689,7 +688,6 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.cb = f->eo.cb;
     so.lookahead = f->eo.lookahead;
     so.slice_between = f->eo.slice_between;
-    so.side_on_chain = f->eo.side_on_chain;
     so.deterministic = f->eo.deterministic;
     so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
     std::vector<int> owner;

@@ -59,7 +59,6 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.cb = opt_.cb;
   so.lookahead = opt_.lookahead;
   so.slice_between = opt_.slice_between;
-  so.side_on_chain = opt_.side_on_chain;
   so.deterministic = opt_.deterministic;
   {
     const bool lb = latency_bound(*S_, std::min(opt_.pw, kPanelMax));
@@ -119,8 +118,7 @@ int Engine::upload() {
   // At most four hardware queues carry the five streams of the program: the runtime
   // multiplexes streams onto a handful of hardware queues, and streams that share one
   // serialise (five queues of our own: no overlap at all, 33.0 ms = the serialized 33.2 ms).
-  // The wide stream only runs when the chains of a level are done -> chain queue; the side
-  // stream exists only in the side-stream variant of the program.
+  // The wide stream only runs when the chains of a level are done -> chain queue.
   auto masked_stream = [&](hipStream_t* st) -> hipError_t {
     if (reserve <= 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo);
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
@@ -129,10 +127,7 @@ int Engine::upload() {
   };
   HIPCHK(hipStreamCreateWithPriority(&streams_[ST_CHAIN], hipStreamNonBlocking, prio_hi), "hipStreamCreate");
   streams_[ST_WIDE] = streams_[ST_CHAIN];
-  if (opt_.side_on_chain || !opt_.lookahead)
-    streams_[ST_SIDE] = streams_[ST_CHAIN];
-  else
-    HIPCHK(hipStreamCreateWithPriority(&streams_[ST_SIDE], hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+  streams_[ST_SIDE] = streams_[ST_CHAIN];
   HIPCHK(masked_stream(&streams_[ST_BULK]), "bulk stream");
   if (std::getenv("SPLLT_FAR_ON_BULK"))   // experiment: three queues
     streams_[ST_FAR] = streams_[ST_BULK];

@@ -21,7 +21,6 @@ struct EngineOptions {
   int cb = 64;             // chain block (edge of the diagonal sub-tiles of the panel chain)
   bool lookahead = true;   // multi-stream program (panel chain overlaps trailing updates)
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
-  bool side_on_chain = true;   // see ScheduleOptions
   bool deterministic = false;  // see ScheduleOptions
   bool poison_lds = false; // debug: poison the LDS of every CU before every launch
   int reserve_cus = -1;    // CUs the bulk / far streams are masked off (0: no mask; -1: 32 when the

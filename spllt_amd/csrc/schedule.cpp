@@ -397,11 +397,10 @@ struct Builder {
     }
 
     const bool la = opt.lookahead;
-    const bool soc = opt.side_on_chain;
     const bool det = opt.deterministic;
     auto edge = [&](int stream) {
       Edge e;
-      e.stream = (!la || (soc && stream == ST_SIDE)) ? ST_CHAIN : stream;
+      e.stream = la ? stream : ST_CHAIN;
       return e;
     };
     std::vector<UpdUnit> us;
@@ -563,8 +562,7 @@ struct Builder {
               }
               L.count = (int64_t)P.chain_units.size() - L.first;
               L.flops = 0;
-              L.stream = (la && !soc) ? ST_SIDE : ST_CHAIN;
-              if (la && !soc) L.add_wait(evCH);
+              L.stream = ST_CHAIN;
               if (L.count > 0) P.launches.push_back(L);
             }
             for (int s : nodes) {
@@ -605,28 +603,24 @@ struct Builder {
               fl += ft + fu;
             }
             if (!us.empty()) {
-              Edge e = edge(ST_SIDE);
-              if (la && !soc) e.wait0 = evCH;
-              emit_gemm(lev, us, fl, false, e);
+              emit_gemm(lev, us, fl, false, edge(ST_CHAIN));
             }
           }
-          // (3) the chunk is final once the side stream has seen its last chain step
+          // (3) the chunk is final: marker event on the chain stream
           int evD = -1;
           if (la) {
             Launch M;
             M.kind = L_GEMM; M.level = lev; M.first = 0; M.count = 0; M.tile = 64; M.flops = 0;
-            M.stream = soc ? ST_CHAIN : ST_SIDE;
-            if (!soc) M.add_wait(evCH);
+            M.stream = ST_CHAIN;
             evD = P.nevents++;
             M.record = evD;
             P.launches.push_back(M);
             evD_last = evD;
           }
-          // (4) updates by the finished chunk.  The next diagonal sub-tile gates the
-          // chain (chain stream); the rest of the near zone -- the remainder of this
-          // block column, or of block column c+1 after the last chunk -- goes to the
-          // side stream; block columns c+2.. to the bulk stream, where they overlap
-          // the chain of block column c+1.
+          // (4) updates by the finished chunk, left-looking inside the block column: the next
+          // chunk's columns by everything left of them (chain stream: small launches that fit
+          // the reserved CUs).  After the last chunk the whole block column updates block
+          // column c+1 (chain stream) and c+2.. (bulk stream, beside the chain of c+1).
           std::vector<UpdUnit> us_n1, us_n2, us_bulk;
           double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0;
           bool to_next_bcol = false;
@@ -638,24 +632,10 @@ struct Builder {
             if (cs >= B.width) continue;
             const int ce = std::min(B.width, cs + cb);
             if (ce < B.width) {
-              // inside the block column: K = this chunk
               const int ce2 = std::min(B.width, ce + cb);
-              if (soc) {
-                // one launch, left-looking: only the next chunk's columns, by everything before
-                // them (K = [0, ce)): the launch stays small enough for the reserved CUs
-                UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
-                us_n1.push_back(n1);
-                fl_n1 += direct_flops(n1);
-                continue;
-              }
-              UpdUnit n1 = direct_unit(b, cs, ce - cs, b, ce, ce2 - ce, ce, ce2 - ce);
+              UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
               us_n1.push_back(n1);
               fl_n1 += direct_flops(n1);
-              if (B.nrow > ce2) {
-                UpdUnit n2 = direct_unit(b, cs, ce - cs, b, ce2, B.nrow - ce2, ce, B.width - ce);
-                us_n2.push_back(n2);
-                fl_n2 += direct_flops(n2);
-              }
             } else {
               // last chunk: the whole block column updates the node's later block columns
               for (int jj = c + 1; jj < nc; ++jj) {
@@ -663,21 +643,9 @@ struct Builder {
                 const BlockCol& D = S.bcols[bd];
                 if (jj == c + 1) {
                   to_next_bcol = true;
-                  const int ce0 = soc ? D.nrow : std::min(cb, D.width);
-                  if (soc) {   // one launch: the whole next block column
-                    UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
-                    us_n1.push_back(n1);
-                    fl_n1 += direct_flops(n1);
-                    continue;
-                  }
-                  UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, ce0, 0, ce0);
+                  UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
                   us_n1.push_back(n1);
                   fl_n1 += direct_flops(n1);
-                  if (D.nrow > ce0) {
-                    UpdUnit n2 = direct_unit(b, 0, B.width, bd, ce0, D.nrow - ce0, 0, D.width);
-                    us_n2.push_back(n2);
-                    fl_n2 += direct_flops(n2);
-                  }
                 } else {
                   UpdUnit u = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
                   // zones of the level below may still be adding into this block column
@@ -700,14 +668,7 @@ struct Builder {
             }
             emit_gemm(lev, us_n1, fl_n1, true, e);
           }
-          if (!us_n2.empty()) {
-            Edge e = edge(ST_SIDE);
-            if (la && to_next_bcol) {
-              e.wait0 = evB_c1;
-              e.wait1 = zev(c + 1);
-            }
-            emit_gemm(lev, us_n2, fl_n2, true, e);
-          }
+          if (!us_n2.empty()) emit_gemm(lev, us_n2, fl_n2, true, edge(ST_CHAIN));   // single-stream program only
           if (g + 1 == ng) {
             int evB = -1;
             if (!us_bulk.empty()) {

@@ -118,7 +118,8 @@ static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_am
 enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5, L_GATHER = 6 };
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
-// the side stream (rows below the sub-tiles: off the critical path by one step), the bulk and
+// (the side stream id is reserved: a variant that ran the rows below the sub-tiles one step
+// behind the chain on their own queue was measured slower and removed), the bulk and
 // far streams (trailing / early inter-node updates that run BESIDE a chain: the engine masks
 // them off a few CUs so that chain and side kernels always find a free CU) and the wide stream
 // (launches that have the chip to themselves: no mask)
@@ -183,9 +184,6 @@ struct ScheduleOptions {
                               // of a level that starts this way subtract with atomics
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
-  bool side_on_chain = true;  // the rows below the sub-tiles and the near-zone updates stay on the
-                              // chain stream: more kernels in the chain, no cross-stream hand-offs
-                              // (each costs 10-20 us) inside it
 };
 
 // Winv slot of panel p of a block column of width w (doubles from the block column's slot 0)
