@@ -115,9 +115,11 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * kernel launch (a kernel that reads LDS it has not written then computes NaNs),
  * bit 8 = no CU reservation (default: the streams that carry the trailing updates
  * are masked off 16 CUs, which the latency-critical panel-chain kernels then find
- * free).  (Bit 9 selected a variant that ran the rows below the diagonal sub-tiles on a
- * side stream one step behind the chain: slower - every cross-stream hand-off costs
- * 10-20 us - and removed; the bit is ignored.)
+ * free).  Bit 9 = no fused panel launches: by default a panel step whose block columns have
+ * few rows below the panel (at most 64 blocks of 64 rows in the launch) runs as ONE kernel -
+ * every workgroup factors the 64 x 64 diagonal block itself, solves its own rows and applies
+ * the left-looking update of the next panel's columns to them - instead of a POTRF, a TRSM
+ * and an update launch (used when the chain block is one panel, the default).
  * Bit 10 / bit 11 = force the zone pipeline on / off (inter-node updates at the end
  * of a level issued by destination block column so that the next level's panel chains
  * start beside them; default: on for latency-bound problems, see schedule.hpp).

@@ -29,6 +29,9 @@ UPD_UNIT_DTYPE = np.dtype([
 UPD_TILE_DTYPE = np.dtype([("unit", "<i4"), ("ti", "<i2"), ("tj", "<i2")])
 CHAIN_UNIT_DTYPE = np.dtype([("off", "<i8"), ("winv_off", "<i8"), ("ld", "<i4"), ("c0", "<i4"),
                              ("pn", "<i4"), ("cs", "<i4"), ("ce", "<i4"), ("gcol", "<i4")])
+PANEL_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"),
+                             ("ld", "<i4"), ("c0", "<i4"), ("pn", "<i4"), ("next_pn", "<i4"),
+                             ("nrow", "<i4"), ("gcol", "<i4"), ("ntile", "<i4"), ("pad_", "<i4")])
 GATHER_ITEM_DTYPE = np.dtype([("buf_off", "<i8"), ("relrow_off", "<i8"), ("gcol_off", "<i8"), ("ld", "<i4"),
                               ("i0", "<i4"), ("i1", "<i4"), ("j0", "<i4"), ("j1", "<i4"),
                               ("diag_shift", "<i4"), ("lower", "<i4"), ("pad_", "<i4")])
@@ -158,6 +161,8 @@ class Factorization:
             return raw.view(POTRF_UNIT_DTYPE)
         if name == "chains":
             return raw.view(CHAIN_UNIT_DTYPE)
+        if name == "panels":
+            return raw.view(PANEL_UNIT_DTYPE)
         if name in ("chain_block", "scratch_size"):
             return int(raw.view(np.int64)[0])
         if name == "gather_tiles":

@@ -550,6 +550,7 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 256) f->eo.reserve_cus = 0;   // bit 8 set: no CU reservation for the chain
   if (flags & 1024) f->eo.zones = 1;        // bit 10 / 11: force the zone pipeline (and the atomic
   if (flags & 2048) f->eo.zones = 0;        // trailing updates that go with it) on / off
+  f->eo.fused_panel = (flags & 512) == 0;   // bit 9 set: no fused panel launches (POTRF, TRSM, update apart)
   f->eo.deterministic = (flags & 4096) != 0;  // bit 12: no atomics (buffer + ordered gather)
   return 0;
 }
@@ -689,6 +690,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
     so.lookahead = f->eo.lookahead;
     so.slice_between = f->eo.slice_between;
     so.deterministic = f->eo.deterministic;
+    so.fused_panel = f->eo.fused_panel;
     so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
     std::vector<int> owner;
     if (f->eo.nranks > 1) {
@@ -719,6 +721,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "units") return raw(P->units.data(), P->units.size() * sizeof(UpdUnit));
   if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
+  if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelUnit));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
   if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }
   if (k == "gather_tiles") return raw(P->gather_tiles.data(), P->gather_tiles.size() * sizeof(GatherTile));

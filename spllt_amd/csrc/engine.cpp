@@ -60,6 +60,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   so.lookahead = opt_.lookahead;
   so.slice_between = opt_.slice_between;
   so.deterministic = opt_.deterministic;
+  so.fused_panel = opt_.fused_panel;
   {
     const bool lb = latency_bound(*S_, std::min(opt_.pw, kPanelMax));
     if (opt_.reserve_cus < 0) opt_.reserve_cus = lb ? 32 : 0;
@@ -189,6 +190,12 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_gitems_, prog_.gather_items), "upload gather items");
   HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
   HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
+  HIPCHK(dev_upload(&d_panel_, prog_.panel_units), "upload panel units");
+  {
+    const size_t bytes = sizeof(int) * 2 * std::max<size_t>(1, prog_.panel_units.size());
+    HIPCHK(hipMalloc((void**)&d_panel_cnt_, bytes), "hipMalloc(panel counters)");
+    HIPCHK(hipMemset(d_panel_cnt_, 0, bytes), "memset(panel counters)");
+  }
   HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
@@ -201,7 +208,7 @@ Engine::~Engine() {
     if (st) hipStreamSynchronize(st);
   for (auto& e : dag_events_) if (e) hipEventDestroy(e);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
+  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_panel_); hipFree(d_panel_cnt_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
   hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
   if (h_flag_) hipHostFree(h_flag_);
@@ -226,6 +233,8 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       launch_chain_panel(st, d_chain_ + l.first, l.count, l.tile, d_L_, d_dinv_, d_flag_);
     } else if (l.kind == L_WINV) {
       launch_winv(st, d_chain_ + l.first, l.count, d_L_, d_dinv_);
+    } else if (l.kind == L_PANEL) {
+      launch_panel(st, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
     } else if (l.kind == L_GATHER) {
       launch_gather(st, d_gtiles_ + l.first, l.count, d_gitems_, d_L_, d_scratch_, d_relpos_, d_rlist_);
     } else {

@@ -22,6 +22,7 @@ struct EngineOptions {
   bool lookahead = true;   // multi-stream program (panel chain overlaps trailing updates)
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
   bool deterministic = false;  // see ScheduleOptions
+  bool fused_panel = true;     // see ScheduleOptions
   bool poison_lds = false; // debug: poison the LDS of every CU before every launch
   int reserve_cus = -1;    // CUs the bulk / far streams are masked off (0: no mask; -1: 32 when the
                            // problem is latency-bound (schedule.hpp), else 0)
@@ -132,6 +133,8 @@ class Engine {
   UpdUnit* d_units_ = nullptr;
   UpdTile* d_tiles_ = nullptr;
   ChainUnit* d_chain_ = nullptr;
+  PanelUnit* d_panel_ = nullptr;
+  int* d_panel_cnt_ = nullptr;     // two "last reader" counters per panel unit (zero between launches)
   GatherTile* d_gtiles_ = nullptr;
   GatherItem* d_gitems_ = nullptr;
   double* d_scratch_ = nullptr;    // MODE_BUFFER products (deterministic engine)

@@ -252,7 +252,7 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
           DI[J][c * DLD + lr] = wx[c];
           X[(J * 16 + c) * TLD + J * 16 + lr] = wx[c];
         }
-        if (failcol != (1 << 30) && lane == 0) atomicMin(flag, u.gcol + J * 16 + failcol + 1);
+        if (failcol != (1 << 30) && lane == 0 && !(u.flags & 4)) atomicMin(flag, u.gcol + J * 16 + failcol + 1);
       }
     }
     __syncthreads();
@@ -320,13 +320,16 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
     __syncthreads();
   }
   STAMP(15);
+  // flags bit 1: the caller stores L itself; bit 2: redundant copy, neither the inverse is
+  // stored nor a failed pivot reported
   if (li < n) {
+    const bool st_l = do_chol && !(u.flags & 2), st_i = !(u.flags & 4);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = lj0 + e;
       if (j < n) {
-        if (do_chol && j <= li) A[(int64_t)li * ld + j] = T[li * TLD + j];
-        D[(int64_t)li * ldd + j] = X[li * TLD + j];
+        if (st_l && j <= li) A[(int64_t)li * ld + j] = T[li * TLD + j];
+        if (st_i) D[(int64_t)li * ldd + j] = X[li * TLD + j];
       }
     }
   }
@@ -479,6 +482,196 @@ __global__ __launch_bounds__(kChainThreads) void k_chain_panel(const ChainUnit* 
     }
   }
   STAMP(20);
+}
+
+// ---------------------------------------------------------------------------
+// One whole panel step of a block column in ONE launch (PanelUnit, tiles = 64-row blocks of
+// the rows below the panel), for the latency-bound levels of the tree: every workgroup
+//   1. factors the panel's diagonal block itself (redundantly: ~24 us that would otherwise
+//      be a launch of its own),
+//   2. solves its own rows:            X_i = A[i, panel] inv(L_pp)^T          (a12)
+//   3. solves the NEXT panel's pivot rows the same way (redundantly, in LDS),
+//   4. applies the left-looking update of the next panel's columns to its own rows:
+//      A[i, next] -= [X_i(:, 0:c0) | X_i] [X_d(:, 0:c0) | X_d]^T              (a13)
+// so that per panel one kernel boundary is on the critical path instead of three (POTRF,
+// TRSM, in-panel update).  No workgroup waits for another one: everything a workgroup reads
+// was final before the launch or is recomputed by itself.  The two blocks that several
+// workgroups READ and that the step OVERWRITES -- the diagonal block (becomes L_pp) and the
+// next pivot rows of the panel's columns (become X_d) -- are written by whichever workgroup
+// read them LAST (a counter per unit; all workgroups hold bit-identical results), so a
+// workgroup that starts late (more workgroups than free CUs) still finds them unsolved.
+// LDS: PotrfShared (T is reused for X_i once the factor is done, X for staging once the
+// inverse is no longer needed) + two 64 x TLD buffers behind it (dynamic).
+// ---------------------------------------------------------------------------
+constexpr int kPanelThreads = 512;
+
+// 64 x 64 block at src (row stride ld) -> dst[64][TLD]; rows >= nrow / columns >= ncol zeroed
+// (unconditional loads at clamped addresses, selection afterwards; 8 lanes read 64 contiguous bytes)
+__device__ __forceinline__ void stage_block(double* __restrict__ dst, const double* __restrict__ src,
+                                            int64_t ld, int nrow, int ncol, int tid) {
+  const int r = tid >> 3, cl = tid & 7;
+  const double* row = src + (int64_t)(r < nrow ? r : nrow - 1) * ld;
+  double v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = row[cl + 8 * e < ncol ? cl + 8 * e : ncol - 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[r * TLD + cl + 8 * e] = (r < nrow && cl + 8 * e < ncol) ? v[e] : 0.0;
+}
+
+// out[16 s + .][16 jb + .] (two column blocks jb0, jb0+1) += sum_k a[row][k] b[col][k] over 64 k
+__device__ __forceinline__ void mma_64(const double* __restrict__ a, const double* __restrict__ b, int s,
+                                       int jb0, int lane, d4& acc0, d4& acc1) {
+  const int lq = lane >> 4, lr = lane & 15;
+  double av[16], b0[16], b1[16];
+#pragma unroll
+  for (int kt = 0; kt < 16; ++kt) {
+    av[kt] = a[(s * 16 + lr) * TLD + 4 * kt + lq];
+    b0[kt] = b[(jb0 * 16 + lr) * TLD + 4 * kt + lq];
+    b1[kt] = b[((jb0 + 1) * 16 + lr) * TLD + 4 * kt + lq];
+  }
+#pragma unroll
+  for (int kt = 0; kt < 16; ++kt) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b0[kt], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b1[kt], acc1, 0, 0, 0);
+  }
+}
+
+// "I have read the shared block": true for the workgroup that says so last (it also clears the
+// counter for the next factorization).  Called by all threads after a barrier that follows the
+// reads; the result is workgroup-uniform.
+__device__ __forceinline__ bool last_reader(int* __restrict__ counter, int readers, int* __restrict__ slot) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int old = atomicAdd(counter, 1);
+    const bool last = old == readers - 1;
+    if (last) atomicExch(counter, 0);
+    *slot = last ? 1 : 0;
+  }
+  __syncthreads();
+  const bool last = *slot != 0;
+  __syncthreads();
+  return last;
+}
+
+__global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restrict__ tiles,
+                                                         const PanelUnit* __restrict__ units,
+                                                         double* __restrict__ L,
+                                                         double* __restrict__ dinv,
+                                                         int* __restrict__ counters,
+                                                         int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) double panel_smem[];
+  __shared__ int vote;
+  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(panel_smem);
+  double* Ui = sh.T;                                          // X_i (T is dead after the factorization)
+  double* Ud = panel_smem + sizeof(PotrfShared) / sizeof(double);  // X_d
+  double* S = Ud + 64 * TLD;                                  // staging
+  __builtin_amdgcn_s_setprio(3);
+  const UpdTile tl = tiles[blockIdx.x];
+  const PanelUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int ld = u.ld, c0 = u.c0, pn = u.pn;
+  double* A = L + u.off;
+  const bool first = tl.ti == 0;
+  // ---- 1. the panel's diagonal block (the first workgroup stores the inverse and reports a
+  // failed pivot; L_pp goes home from the workgroup that read the block last) ---------------
+  double* Dg = A + (int64_t)c0 * ld + c0;
+  potrf64_body(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? 2 : 6, flag);
+  __syncthreads();
+  if (last_reader(counters + 2 * tl.unit, u.ntile, &vote)) {
+    const int li = tid >> 3, lj0 = (tid & 7) * 8;
+    if (li < pn) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = lj0 + e;
+        if (j <= li) Dg[(int64_t)li * ld + j] = sh.T[li * TLD + j];
+      }
+    }
+    __syncthreads();
+  }
+  const int r1 = c0 + pn;                  // first row below the panel
+  const int r0 = r1 + 64 * (int)tl.ti;     // first row of this workgroup's block
+  const int nr = min(64, u.nrow - r0);     // (<= 0: the block column ends with the panel)
+  if (nr <= 0) return;
+  const int pn2 = u.next_pn;
+  const int s = wave >> 1, jb0 = (wave & 1) * 2;   // this wave's 16-row strip and two 16-column blocks
+  // ---- 2. X_i = A[r0.., panel] inv(L_pp)^T ---------------------------------------------
+  stage_block(S, A + (int64_t)r0 * ld + c0, ld, nr, pn, tid);
+  __syncthreads();
+  // the next panel's pivot rows are the first pn2 rows of the first block: every other
+  // workgroup reads them unsolved in step 3
+  bool store_pivot = pn2 > 0 && first && last_reader(counters + 2 * tl.unit + 1, u.ntile, &vote);
+  {
+    d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+    mma_64(S, sh.X, s, jb0, lane, a0, a1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = s * 16 + lq + 4 * r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = (jb0 + h) * 16 + lr;
+        const double v = (j < pn) ? (h ? a1[r] : a0[r]) : 0.0;   // padding columns: exact zeros
+        Ui[i * TLD + j] = v;
+        const bool mine = !first || i >= pn2 || store_pivot;
+        if (mine && i < nr && j < pn) A[(int64_t)(r0 + i) * ld + c0 + j] = v;
+      }
+    }
+  }
+  if (pn2 <= 0) return;                    // last panel of the block column: nothing to update
+  __syncthreads();                         // S and X are free again; Ui is complete
+  // ---- 3. X_d: the next panel's pivot rows, solved the same way ---------------------------
+  const double* Xd = Ui;
+  if (!first) {
+    stage_block(S, A + (int64_t)r1 * ld + c0, ld, pn2, pn, tid);
+    __syncthreads();
+    store_pivot = last_reader(counters + 2 * tl.unit + 1, u.ntile, &vote);
+    d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+    mma_64(S, sh.X, s, jb0, lane, a0, a1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = s * 16 + lq + 4 * r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = (jb0 + h) * 16 + lr;
+        const double v = (j < pn) ? (h ? a1[r] : a0[r]) : 0.0;
+        Ud[i * TLD + j] = v;
+        if (store_pivot && i < pn2 && j < pn) A[(int64_t)(r1 + i) * ld + c0 + j] = v;
+      }
+    }
+    Xd = Ud;
+    __syncthreads();
+  }
+  // ---- 4. A[r0.., next panel] -= [X_i(:, 0:c0) | X_i] [X_d(:, 0:c0) | X_d]^T (lower part) ----
+  const int cn = r1;                       // first column of the next panel (= its first pivot row)
+  d4 c0v, c1v;
+  bool ok0[4], ok1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = s * 16 + lq + 4 * r;
+    const int j0 = jb0 * 16 + lr, j1 = j0 + 16;
+    ok0[r] = i < nr && j0 < pn2 && (r0 + i) >= (cn + j0);
+    ok1[r] = i < nr && j1 < pn2 && (r0 + i) >= (cn + j1);
+    const double* crow = A + (int64_t)(r0 + (i < nr ? i : nr - 1)) * ld + cn;
+    c0v[r] = crow[j0 < pn2 ? j0 : pn2 - 1];       // unconditional, clamped
+    c1v[r] = crow[j1 < pn2 ? j1 : pn2 - 1];
+  }
+  d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+  double* Sa = sh.X;                        // the inverse is no longer needed: staging for the own rows
+  for (int k0 = 0; k0 < c0; k0 += 64) {
+    const int kw = min(64, c0 - k0);
+    stage_block(Sa, A + (int64_t)r0 * ld + k0, ld, nr, kw, tid);
+    stage_block(S, A + (int64_t)r1 * ld + k0, ld, pn2, kw, tid);
+    __syncthreads();
+    mma_64(Sa, S, s, jb0, lane, m0, m1);
+    __syncthreads();
+  }
+  mma_64(Ui, Xd, s, jb0, lane, m0, m1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = s * 16 + lq + 4 * r;
+    double* crow = A + (int64_t)(r0 + (i < nr ? i : nr - 1)) * ld + cn;
+    if (ok0[r]) crow[jb0 * 16 + lr] = c0v[r] - m0[r];
+    if (ok1[r]) crow[jb0 * 16 + 16 + lr] = c1v[r] - m1[r];
+  }
 }
 
 // W part of Winv for the panels of a launch of k_chain_panel (same ChainUnit): one workgroup
@@ -1164,6 +1357,21 @@ void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, i
   }
   hipLaunchKernelGGL(k_chain_panel, dim3((unsigned)count), dim3(kChainThreads), chain_lds_bytes(max_rows_below),
                      st, units, L, dinv, flag);
+}
+
+void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
+                  double* dinv, int* counters, int* flag) {
+  if (count <= 0) return;
+  const unsigned lds = (unsigned)(sizeof(PotrfShared) + sizeof(double) * 2 * 64 * TLD);
+  thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    (void)hipFuncSetAttribute((const void*)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(k_panel, dim3((unsigned)count), dim3(kPanelThreads), lds, st, tiles, units, L, dinv, counters,
+                     flag);
 }
 
 void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv) {

@@ -41,6 +41,8 @@ struct OpsBatch {
     UpdTile* d_tiles = nullptr;
     PotrfUnit* d_potrf = nullptr;
     ChainUnit* d_chain = nullptr;
+    PanelUnit* d_panel = nullptr;
+    int* d_pcnt = nullptr;
     double* d_dinv = nullptr;
     int* d_flag = dev_flag;
     bool own_flag = false;
@@ -60,6 +62,11 @@ struct OpsBatch {
     up((void**)&d_tiles, P.tiles.data(), P.tiles.size() * sizeof(UpdTile));
     up((void**)&d_potrf, P.potrf_units.data(), P.potrf_units.size() * sizeof(PotrfUnit));
     up((void**)&d_chain, P.chain_units.data(), P.chain_units.size() * sizeof(ChainUnit));
+    up((void**)&d_panel, P.panel_units.data(), P.panel_units.size() * sizeof(PanelUnit));
+    {
+      std::vector<int> zeros(2 * std::max<size_t>(1, P.panel_units.size()), 0);
+      up((void**)&d_pcnt, zeros.data(), zeros.size() * sizeof(int));
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * std::max<int64_t>(1, P.dinv_size));
     if (e == hipSuccess && !d_flag) {
       own_flag = true;
@@ -77,6 +84,8 @@ struct OpsBatch {
           launch_chain_panel(st, d_chain + l.first, l.count, l.tile, base, d_dinv, d_flag);
         else if (l.kind == L_WINV)
           launch_winv(st, d_chain + l.first, l.count, base, d_dinv);
+        else if (l.kind == L_PANEL)
+          launch_panel(st, d_tiles + l.first, l.count, d_panel, base, d_dinv, d_pcnt, d_flag);
         else
           launch_update(st, l.tile, d_tiles + l.first, l.count, d_units, d_off, d_w, base, relpos,
                         rlist, d_dinv);
@@ -85,7 +94,7 @@ struct OpsBatch {
       hipError_t e2 = hipStreamSynchronize(st);
       if (e == hipSuccess) e = e2;
     }
-    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_chain); hipFree(d_dinv);
+    hipFree(d_off); hipFree(d_w); hipFree(d_units); hipFree(d_tiles); hipFree(d_potrf); hipFree(d_chain); hipFree(d_panel); hipFree(d_pcnt); hipFree(d_dinv);
     if (own_flag) hipFree(d_flag);
     if (e != hipSuccess) {
       std::fprintf(stderr, "spllt-hip: operator failed: %s\n", hipGetErrorString(e));

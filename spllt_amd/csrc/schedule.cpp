@@ -395,6 +395,7 @@ struct Builder {
       dinv_slot[S.nbcol()] = o;
       P.dinv_size = o;
     }
+    const int64_t fused_max = env_int("SPLLT_FUSED_PANEL_MAX", opt.fused_panel_max);
 
     const bool la = opt.lookahead;
     const bool det = opt.deterministic;
@@ -469,6 +470,18 @@ struct Builder {
           if (c < nc) maxw = std::max(maxw, S.bcols[S.node_bcol0[s] + c].width);
         }
         const int ng = cdiv(maxw, cb);
+        // Latency-bound step (few row blocks below the panels): one fused launch per panel
+        bool fuse_c = false;
+        if (opt.fused_panel && cb == pw && pw <= 64) {
+          int64_t nt = 0;
+          for (int s : nodes) {
+            const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+            if (c >= nc) continue;
+            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
+            nt += std::max(1, cdiv(B.nrow - std::min(pw, B.width), 64));
+          }
+          fuse_c = nt <= fused_max;
+        }
         const int evB_c2 = (la && c >= 2) ? evB_hist[c - 2] : -1;   // bulk (c-2 -> c..)
         const int evB_c1 = (la && c >= 1) ? evB_hist[c - 1] : -1;   // bulk (c-1 -> c+1..)
         for (int g = 0; g < ng; ++g) {
@@ -481,7 +494,56 @@ struct Builder {
             if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pw));
           }
           int evCH = -1;
-          for (int q = 0; q < maxq; ++q) {
+          if (fuse_c) {
+            // the whole panel step in one launch (k_panel): POTRF, the rows below, and the
+            // left-looking update of the next panel's columns
+            Launch L;
+            L.kind = L_PANEL;
+            L.level = lev;
+            L.first = (int64_t)P.tiles.size();
+            L.tile = 64;
+            double fl = 0;
+            for (int s : nodes) {
+              const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              const int b = S.node_bcol0[s] + c;
+              const BlockCol& B = S.bcols[b];
+              const int c0 = cs;
+              if (c0 >= B.width) continue;
+              const int pn = std::min(pw, B.width - c0);
+              const int next_pn = std::min(pw, B.width - c0 - pn);
+              const int below = B.nrow - c0 - pn;
+              PanelUnit u{};
+              u.off = B.off;
+              u.dinv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
+              u.ld = B.width;
+              u.c0 = c0;
+              u.pn = pn;
+              u.next_pn = next_pn;
+              u.nrow = B.nrow;
+              u.gcol = S.sptr[s] + B.r0 + c0;
+              const int nt = std::max(1, cdiv(below, 64));
+              u.ntile = nt;
+              const int ui = (int)P.panel_units.size();
+              P.panel_units.push_back(u);
+              for (int t = 0; t < nt; ++t) P.tiles.push_back(UpdTile{ui, (short)t, 0});
+              const double fp = (double)pn * pn * pn / 3.0, ft = (double)below * pn * pn;
+              const double fu = 2.0 * (c0 + pn) * ((double)below * next_pn - 0.5 * next_pn * (next_pn - 1));
+              P.flops_potrf += fp;
+              P.flops_trsm += ft;
+              P.flops_update += fu;
+              fl += fp + ft + fu;
+            }
+            L.count = (int64_t)P.tiles.size() - L.first;
+            L.flops = fl;
+            L.stream = ST_CHAIN;
+            if (la && g == 0) {
+              L.add_wait(zev(c));    // every inter-node update into block column c
+              L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
+            }
+            if (L.count > 0) P.launches.push_back(L);
+          }
+          for (int q = 0; !fuse_c && q < maxq; ++q) {
             // (1) chain step: panel q of the sub-tile, one workgroup per node
             {
               Launch L;
@@ -632,6 +694,7 @@ struct Builder {
             if (cs >= B.width) continue;
             const int ce = std::min(B.width, cs + cb);
             if (ce < B.width) {
+              if (fuse_c) continue;   // part of the panel launch
               const int ce2 = std::min(B.width, ce + cb);
               UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
               us_n1.push_back(n1);

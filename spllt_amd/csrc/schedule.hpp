@@ -90,6 +90,22 @@ struct ChainUnit {
 };
 static_assert(sizeof(ChainUnit) == 40, "ChainUnit layout (mirrored in spllt_amd/api.py)");
 
+// One whole panel step of a block column (k_panel): POTRF of the panel [c0, c0+pn), solve of
+// all rows below it, left-looking update of the next panel's columns (next_pn of them; 0: the
+// panel is the last of its block column).  The inverse goes to dinv_off (pn x pn).
+struct PanelUnit {
+  int64_t off;       // arena offset of the block column
+  int64_t dinv_off;
+  int ld;            // block column width
+  int c0, pn;
+  int next_pn;
+  int nrow;          // rows of the block column
+  int gcol;          // pivot position of column c0 (error reporting)
+  int ntile;         // workgroups of the unit (64-row blocks below the panel, at least one)
+  int pad_;
+};
+static_assert(sizeof(PanelUnit) == 48, "PanelUnit layout (mirrored in spllt_amd/api.py)");
+
 // Deterministic assembly (k_gather): one workgroup per destination tile (<= 64 x 64 entries of
 // a block column) walks its items in order; an item is the part of one buffered update block
 // (MODE_BUFFER unit) that lands in the tile.
@@ -115,7 +131,8 @@ struct GatherTile {
 };
 static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5, L_GATHER = 6 };
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5, L_GATHER = 6,
+                        L_PANEL = 7 };
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
 // (the side stream id is reserved: a variant that ran the rows below the sub-tiles one step
@@ -151,6 +168,7 @@ struct Program {
   int cb = 64;  // chain block: edge of the diagonal sub-tiles the chain kernels walk
   std::vector<PotrfUnit> potrf_units;  // L_POTRF (operator twins only: inverse of given factors)
   std::vector<ChainUnit> chain_units;  // L_CHAIN, L_WINV
+  std::vector<PanelUnit> panel_units;  // L_PANEL (tiles: unit, ti)
   std::vector<GatherItem> gather_items;
   std::vector<GatherTile> gather_tiles;  // L_GATHER
   int64_t scratch_size = 0;     // doubles of the MODE_BUFFER scratch (largest launch)
@@ -182,6 +200,12 @@ struct ScheduleOptions {
                               // sorted by destination block column, one event per zone, so that
                               // the next level's chains start beside them; the trailing updates
                               // of a level that starts this way subtract with atomics
+  bool fused_panel = true;    // steps with few row blocks below the panels: one k_panel launch per panel
+  int fused_panel_max = 64;   // ... when the launch has at most this many workgroups.  (k_panel needs a
+                              // whole CU per workgroup; beside the trailing updates only the reserved
+                              // CUs are free, and a launch that needs a second round of them loses
+                              // what the two saved kernel boundaries gain: 26.3 ms unfused, 25.9 with
+                              // 64, 26.3 with 128, 28.4 with 512 on the nd24k stand-in)
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
 };

@@ -87,6 +87,42 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                     keep = np.tril(np.ones((ce - c0 - pn,) * 2, dtype=bool))
                     arena[ti[keep]] -= (X @ X.T)[keep]
             continue
+        if kind == 7:  # one whole panel step per launch (k_panel), workgroup by workgroup
+            pu = f.program("panels")
+            snap = arena.copy()      # every workgroup reads the state before the launch
+            for t in tiles[first:first + count]:
+                q = pu[int(t["unit"])]
+                ld, off, nrow = int(q["ld"]), int(q["off"]), int(q["nrow"])
+                c0, pn, pn2 = int(q["c0"]), int(q["pn"]), int(q["next_pn"])
+
+                def idx(r0, r1, k0, k1):
+                    return off + np.arange(r0, r1)[:, None] * ld + np.arange(k0, k1)[None, :]
+                dd = idx(c0, c0 + pn, c0, c0 + pn)
+                blk = np.tril(snap[dd])
+                Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
+                inv = sl.solve_triangular(Lb, np.eye(pn), lower=True)
+                ti = int(t["ti"])
+                if ti == 0:
+                    low = np.tril_indices(pn)
+                    arena[dd[low]] = Lb[low]
+                    do = int(q["dinv_off"])
+                    dinv[do:do + pn * pn] = inv.ravel()
+                r1 = c0 + pn
+                r0 = r1 + 64 * ti
+                nr = min(64, nrow - r0)
+                if nr <= 0:
+                    continue
+                Xi = snap[idx(r0, r0 + nr, c0, r1)] @ inv.T
+                arena[idx(r0, r0 + nr, c0, r1)] = Xi
+                if pn2 <= 0:
+                    continue
+                Xd = snap[idx(r1, r1 + pn2, c0, r1)] @ inv.T
+                upd = (np.hstack([snap[idx(r0, r0 + nr, 0, c0)], Xi]) @
+                       np.hstack([snap[idx(r1, r1 + pn2, 0, c0)], Xd]).T)
+                ci = idx(r0, r0 + nr, r1, r1 + pn2)
+                keep = (r0 + np.arange(nr))[:, None] >= (r1 + np.arange(pn2))[None, :]
+                arena[ci[keep]] = snap[ci[keep]] - upd[keep]
+            continue
         if kind == 6:  # ordered gather of buffered update blocks into destination tiles (k_gather)
             gt, gi = f.program("gather_tiles"), f.program("gather_items")
             for t in gt[first:first + count]:

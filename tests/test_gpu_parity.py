@@ -510,11 +510,12 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("flags", [2, 64, 66, 256, 1024, 2048, 4096, 4098])
+@pytest.mark.parametrize("flags", [2, 64, 66, 256, 512, 1024, 2048, 4096, 4098])
 @pytest.mark.parametrize("cb", [None, 32, 96, 160])
 def test_engine_variants_match_oracle(flags, cb):
     """single-stream program (2), inter-node updates only at the end of a level (64), both
-    (66), no CU reservation (256), zone pipeline forced on / off (1024 / 2048), deterministic
+    (66), no CU reservation (256), no fused panel launches (512; they are used when the chain
+    block is one panel, cb = 32 here), zone pipeline forced on / off (1024 / 2048), deterministic
     (4096); chain block = one panel (default), several panels per sub-tile, whole block columns."""
     A = matgen.nd_like((12, 11, 10), 2)
     f, val = make_case(A, nb=160, nemin=16, panel_width=32, engine_flags=flags, chain_block=cb)
@@ -523,6 +524,28 @@ def test_engine_variants_match_oracle(flags, cb):
     o, rc = oracle_factor(f, val)
     assert rc == 0
     assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
+
+
+@pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson3d(40), 384), (lambda: matgen.fe27((20, 20, 18), 3), 256)])
+def test_fused_panel_launches_larger_than_the_chip(gen, nb, monkeypatch):
+    """k_panel: the diagonal block and the next pivot rows are read by every workgroup of a
+    unit and overwritten by the step; the workgroup that read them LAST writes them.  With more
+    workgroups in a launch than the chip holds at once (one per CU), late workgroups start after
+    early ones have finished - they must still find the blocks unsolved.  The default only fuses
+    launches of <= 64 workgroups; here every step is fused."""
+    monkeypatch.setenv("SPLLT_FUSED_PANEL_MAX", "1000000")
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=32)
+    L = f.program("launches")
+    assert not (L[:, 0] == 4).any() and (L[(L[:, 0] == 7), 3] > 256).any()
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val, variant="mkl", nthreads=8)
+    assert rc == 0
+    assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    got2 = f.factor(val).wait().get_factor()       # the counters were left at zero
+    assert rel_err(got2, o.arena(), lower_mask(f)) <= TOL_L
     b = A @ np.ones(f.n)
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 

@@ -148,6 +148,26 @@ def _access_sets(f):
                 R.append((b, c0, c0 + pn, cs, c0))
                 R.append(("wi", b, c0 // pw))
                 W.append(("ww", b, c0 // pw))      # W part of Winv
+        elif kind == 7:
+            pu = f.program("panels")
+            tl = tiles[first:first + count]
+            for uid in sorted(set(tl["unit"].tolist())):
+                q = pu[uid]
+                b = bcol_of(q["off"])
+                c0, pn, pn2, nrow = int(q["c0"]), int(q["pn"]), int(q["next_pn"]), int(q["nrow"])
+                r1 = c0 + pn
+                assert int(bw[b]) == q["ld"] and int(bnr[b]) == nrow
+                # every 64-row block below the panel has its workgroup (+ one when there is none)
+                tis = sorted(tl["ti"][(tl["unit"] == uid) & (tl["tj"] == 0)].tolist())
+                assert tis == list(range(max(1, -(-(nrow - r1) // 64)))), (tis, nrow, r1)
+                assert len(tis) == q["ntile"]       # the "last reader" counters count to this
+                R.append((b, c0, nrow, c0, r1))
+                W.append((b, c0, nrow, c0, r1))
+                W.append(("wi", b, c0 // pw))
+                if pn2 > 0:
+                    R.append((b, r1, nrow, 0, c0))
+                    R.append((b, r1, nrow, r1, r1 + pn2))
+                    W.append((b, r1, nrow, r1, r1 + pn2))
         elif kind == 6:
             gt = f.program("gather_tiles")
             R.append(("scratch", 0, 0))
@@ -247,8 +267,8 @@ def dag_violations(f):
                                         (lambda: matgen.poisson3d(9), 24, 8),
                                         (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8),   # many block columns per node
                                         (lambda: matgen.nd_like((9, 8, 8), 2), 100, 8)])
-@pytest.mark.parametrize("cb", [0, 16, 40])
-@pytest.mark.parametrize("flags", [0, 64, 1024, 2048, 4096, 4160])
+@pytest.mark.parametrize("cb", [0, 8, 16, 40])
+@pytest.mark.parametrize("flags", [0, 64, 512, 1024, 2048, 2560, 4096, 4160, 4608])
 def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
     """Multi-stream program (chain, side, bulk, far, wide): any two launches that touch the
     same entries (write/write, read/write, atomic/plain) must be ordered by stream order or
@@ -262,7 +282,9 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
     assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert not (launches[:, 6] == 3).any(), "the side stream is not used"
-    assert (launches[:, 0] == 4).any()
+    eff_cb = max(pw, (max(cb or 64, pw) // pw) * pw)
+    fused = eff_cb == pw and not flags & 512      # fused panel launches replace the chain steps
+    assert (launches[:, 0] == (7 if fused else 4)).any() and not (launches[:, 0] == (4 if fused else 7)).any()
     assert ((launches[:, 0] == 6).any()) == bool(flags & 4096), "gather launches only in the deterministic engine"
     if flags & 4096:
         units = f.program("units")
@@ -284,7 +306,7 @@ def test_single_stream_program_has_no_events():
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
-@pytest.mark.parametrize("flags", [0, 2, 64, 66, 1024, 2048, 4096, 4098])
+@pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048, 4096, 4098, 4608])
 @pytest.mark.parametrize("cb", [0, 16, 32])
 def test_program_variants_agree(flags, cb, monkeypatch):
     """multi-stream / single-stream programs, with and without early inter-node slices, zone
@@ -295,6 +317,8 @@ def test_program_variants_agree(flags, cb, monkeypatch):
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
     assert f.program("chain_block") == (cb or 64) // 16 * 16
+    kinds = f.program("launches")[:, 0]
+    assert (kinds == 7).any() == (cb == 16 and not flags & 512), "fused panel launches: chain block = panel, flag 512 off"
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
