@@ -129,6 +129,8 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * steps, serialised per destination like its OpenMP path, task_mod:1239-1241); two
  * factorizations of the same values then give bit-identical factors.  Implies no zone
  * pipeline and no early slices.
+ * Bit 13 / bit 14 = (multi-GPU) top tree distributed over the ranks / replicated on every rank
+ * (default: by the weight of the top tree, see spllt_hip_set_partition).
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
@@ -141,15 +143,35 @@ int spllt_hip_set_chain_block(void *fkeep, int chain_block);
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------
  * Call after spllt_analyse (options.prune_tree = 1, options.ncpu = nranks) and
  * before the first spllt_factor.  Every rank factorizes the pruned subtrees it
- * owns; spllt_factor then stops at the exchange point with the top-tree block
- * columns packed into the caller's device buffer (exchange_elems doubles; the last one
- * carries the "not positive definite" indicator, so that after the sum every rank
- * reports the same outcome).
- * The caller sums that buffer over all ranks (RCCL all-reduce over xGMI: this
- * is the extend-add that replaces spllt_scatter_block on generated elements,
- * reference src/spllt_factorization_mod.F90:39-191), calls spllt_hip_continue,
- * then spllt_wait/spllt_hip_wait.  The top tree is factorized on every rank. */
+ * owns; spllt_factor then stops at the first EXCHANGE point of the rank's program.  The
+ * caller drives the exchanges:
+ *
+ *   spllt_hip_factor_dev(...);
+ *   while ((k = spllt_hip_pending_exchange(fkeep)) >= 0) {
+ *     <collective of exchange k on the exchange buffer, enqueued on spllt_hip_engine_stream>
+ *     spllt_hip_continue(fkeep);        // unpack, enqueue up to the next exchange, pack
+ *   }
+ *   spllt_hip_wait(fkeep);
+ *
+ * Exchange k is described by spllt_hip_program_get "exchanges" (int64 x 5: kind, first item,
+ * items, elems, chunk) and "xitems" (int64 x 6: block column, root, offset in the buffer, count,
+ * offset in the arena or the dinv scratch, space 0 = arena / 1 = dinv scratch); every rank
+ * has the same list.  kind 0: all-reduce(sum) of buffer[0:elems] - the extend-add of the whole
+ * top tree (replaces spllt_scatter_block on generated elements, reference
+ * src/spllt_factorization_mod.F90:39-191; the last element carries the "not positive definite"
+ * indicator); the top tree is then factorized on every rank (replicated).
+ * Distributed top tree (engine flag bit 13, or chosen by the engine when the top tree is
+ * heavy): kind 1: reduce-scatter(sum) of buffer[0:elems] in nranks chunks, rank r receives chunk
+ * r AT buffer[r*chunk:(r+1)*chunk] (the block columns of the top tree that r owns); kind 2:
+ * for every root with items, broadcast of that root's segment of the buffer (its items are
+ * contiguous) - the block columns of a finished step go from their owners to all ranks, which
+ * then update the destination block columns they own; kind 3: all-reduce(sum) of buffer[0:1],
+ * the "not positive definite" indicator, at the very end.
+ * exchange_elems: doubles the exchange buffer must hold (the largest exchange). */
 int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange_elems);
+/* index of the exchange the handle is waiting for (-1: none, the program has been enqueued
+ * to its end) */
+int spllt_hip_pending_exchange(void *fkeep);
 
 /* Substitution on DEVICE vectors in pivot order: y_dev holds nrhs vectors of
  * length n, y[q*n + p(i)] = b_q[i], p = 0-based pivot position ("order" of spllt_hip_sym_get); overwritten by the solution in the same
@@ -173,6 +195,8 @@ int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
 void *spllt_hip_engine_stream(void *fkeep);
 int spllt_hip_continue(void *fkeep);
 /* "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),
+ * "top_bcol_owner" (int32 per block column: owner in a distributed top tree, -1 outside it;
+ * empty when the top tree is replicated),
  * "map_keep" (uint8 per val->L map entry: scattered on this rank) */
 int64_t spllt_hip_partition_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 

@@ -54,6 +54,7 @@ HIP_SYMBOLS = [
     "spllt_hip_get_factor", "spllt_hip_device_factor", "spllt_hip_factor_times",
     "spllt_hip_program_get", "spllt_hip_profile", "spllt_hip_last_error", "spllt_hip_version",
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
+    "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program",
 ]
 
@@ -133,6 +134,8 @@ def load():
     lib.spllt_hip_set_partition.restype = C.c_int
     lib.spllt_hip_set_exchange_buffer.argtypes = [vp, vp]
     lib.spllt_hip_set_exchange_buffer.restype = C.c_int
+    lib.spllt_hip_pending_exchange.argtypes = [vp]
+    lib.spllt_hip_pending_exchange.restype = C.c_int
     lib.spllt_hip_continue.argtypes = [vp]
     lib.spllt_hip_continue.restype = C.c_int
     lib.spllt_hip_partition_get.argtypes = [vp, C.c_char_p, vp, C.c_int64]

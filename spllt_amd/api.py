@@ -163,6 +163,12 @@ class Factorization:
             return raw.view(CHAIN_UNIT_DTYPE)
         if name == "panels":
             return raw.view(PANEL_UNIT_DTYPE)
+        if name == "exchanges":
+            return raw.view(np.int64).reshape(-1, 5)
+        if name == "xitems":
+            return raw.view(np.int64).reshape(-1, 6)
+        if name == "xbuf_elems":
+            return int(raw.view(np.int64)[0])
         if name in ("chain_block", "scratch_size"):
             return int(raw.view(np.int64)[0])
         if name == "gather_tiles":
@@ -258,6 +264,7 @@ class Factorization:
         rc = self.lib.spllt_hip_set_partition(self.fkeep, rank, nranks, C.byref(n))
         if rc < 0:
             raise SplltError("spllt_hip_set_partition", rc)
+        self.rank, self.nranks = rank, nranks
         return n.value
 
     def set_exchange_buffer(self, dev_ptr):
@@ -277,6 +284,10 @@ class Factorization:
         if rc < 0:
             raise SplltError("spllt_hip_continue", rc, self.last_error())
         return self
+
+    def pending_exchange(self):
+        """index of the exchange (program("exchanges")) the engine is waiting for, -1: none"""
+        return int(self.lib.spllt_hip_pending_exchange(self.fkeep))
 
     def partition(self, name):
         nbytes = self.lib.spllt_hip_partition_get(self.fkeep, name.encode(), None, 0)

@@ -551,7 +551,9 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 1024) f->eo.zones = 1;        // bit 10 / 11: force the zone pipeline (and the atomic
   if (flags & 2048) f->eo.zones = 0;        // trailing updates that go with it) on / off
   f->eo.fused_panel = (flags & 512) == 0;   // bit 9 set: no fused panel launches (POTRF, TRSM, update apart)
-  f->eo.deterministic = (flags & 4096) != 0;  // bit 12: no atomics (buffer + ordered gather)
+  f->eo.deterministic = (flags & 4096) != 0;
+  if (flags & 8192) f->eo.dist_top = 1;     // bit 13 / 14: top tree of a partitioned factorization
+  if (flags & 16384) f->eo.dist_top = 0;    // distributed over the ranks / replicated on every rank  // bit 12: no atomics (buffer + ordered gather)
   return 0;
 }
 
@@ -561,6 +563,22 @@ int spllt_hip_set_chain_block(void* fkeep, int chain_block) {
   if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
   f->eo.cb = chain_block;
   return 0;
+}
+
+// The program of a handle that has no engine (yet): built on the host, no GPU needed.
+static void build_local_program(Fkeep* f, Program& local) {
+  ScheduleOptions so;
+  so.pw = f->eo.pw;
+  so.tile = f->eo.tile;
+  so.cb = f->eo.cb;
+  so.lookahead = f->eo.lookahead;
+  so.slice_between = f->eo.slice_between;
+  so.deterministic = f->eo.deterministic;
+  so.fused_panel = f->eo.fused_panel;
+  so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
+  std::vector<int> owner, top_owner;
+  partition_options(*f->S, f->eo, owner, top_owner, so);
+  build_program(*f->S, so, local);
 }
 
 // ---- multi-GPU partition ---------------------------------------------------
@@ -591,12 +609,14 @@ int spllt_hip_set_partition(void* fkeep, int rank, int nranks, int64_t* exchange
   if (f->eng) return SPLLT_ERROR_PARAMETER;  // too late
   f->eo.rank = rank;
   f->eo.nranks = nranks;
-  std::vector<int> owner, top;
-  std::vector<char> keep;
-  int64_t elems = 0;
-  partition_tables(f, owner, top, keep, elems);
-  // + 1: the element that carries the "not positive definite" indicator across the ranks
-  if (exchange_elems) *exchange_elems = nranks > 1 ? elems + 1 : 0;
+  if (exchange_elems) {
+    *exchange_elems = 0;
+    if (nranks > 1) {   // the largest exchange of this rank's program
+      Program local;
+      build_local_program(f, local);
+      *exchange_elems = local.xbuf_elems;
+    }
+  }
   return 0;
 }
 
@@ -617,6 +637,12 @@ int spllt_hip_set_exchange_buffer(void* fkeep, void* dev_ptr) {
   f->xbuf = static_cast<double*>(dev_ptr);
   if (f->eng) f->eng->set_exchange_buffer(f->xbuf);
   return 0;
+}
+
+int spllt_hip_pending_exchange(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->eng) return -1;
+  return f->eng->pending_exchange();
 }
 
 int spllt_hip_continue(void* fkeep) {
@@ -644,6 +670,12 @@ int64_t spllt_hip_partition_get(void* fkeep, const char* name, void* buf, int64_
     return (int64_t)bytes;
   };
   if (k == "owner") return raw(owner.data(), owner.size() * sizeof(int));
+  if (k == "top_bcol_owner") {   // empty: the top tree is replicated
+    ScheduleOptions so;
+    std::vector<int> o2, top_owner;
+    partition_options(*f->S, f->eo, o2, top_owner, so);
+    return raw(top_owner.data(), top_owner.size() * sizeof(int));
+  }
   if (k == "top_bcols") return raw(top.data(), top.size() * sizeof(int));
   if (k == "map_keep") return raw(keep.data(), keep.size());
   return -1;
@@ -683,23 +715,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (f->eng && !f->eng->status()) {
     P = &f->eng->program();
   } else {
-    ScheduleOptions so;
-    so.pw = f->eo.pw;
-    so.tile = f->eo.tile;
-    so.cb = f->eo.cb;
-    so.lookahead = f->eo.lookahead;
-    so.slice_between = f->eo.slice_between;
-    so.deterministic = f->eo.deterministic;
-    so.fused_panel = f->eo.fused_panel;
-    so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
-    std::vector<int> owner;
-    if (f->eo.nranks > 1) {
-      assign_owners(*f->S, f->eo.nranks, owner);
-      so.node_owner = owner.data();
-      so.rank = f->eo.rank;
-      so.nranks = f->eo.nranks;
-    }
-    build_program(*f->S, so, local);
+    build_local_program(f, local);
     P = &local;
   }
   std::string k(name);
@@ -721,6 +737,22 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "units") return raw(P->units.data(), P->units.size() * sizeof(UpdUnit));
   if (k == "tiles") return raw(P->tiles.data(), P->tiles.size() * sizeof(UpdTile));
   if (k == "relpos") return raw(P->relpos.data(), P->relpos.size() * sizeof(int));
+  if (k == "exchanges") {   // int64 x 5 per exchange: kind, first_item, nitems, elems, chunk
+    std::vector<int64_t> t;
+    for (const Exchange& e : P->exchanges) {
+      t.push_back(e.kind); t.push_back(e.first_item); t.push_back(e.nitems); t.push_back(e.elems); t.push_back(e.chunk);
+    }
+    return raw(t.data(), t.size() * sizeof(int64_t));
+  }
+  if (k == "xitems") {      // int64 x 6 per item: block column, root, offset in the buffer, count,
+    std::vector<int64_t> t; // offset in the arena / dinv scratch, space (0 arena, 1 dinv)
+    for (const ExchangeItem& e : P->xitems) {
+      t.push_back(e.bcol); t.push_back(e.root); t.push_back(e.xoff); t.push_back(e.count);
+      t.push_back(e.off); t.push_back(e.space);
+    }
+    return raw(t.data(), t.size() * sizeof(int64_t));
+  }
+  if (k == "xbuf_elems") return raw(&P->xbuf_elems, sizeof(int64_t));
   if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelUnit));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
   if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }

@@ -41,6 +41,25 @@ static hipError_t dev_upload(Tp** dptr, const std::vector<Tp>& v) {
   return e;
 }
 
+void partition_options(const Symbolic& S, const EngineOptions& opt, std::vector<int>& owner,
+                       std::vector<int>& top_owner, ScheduleOptions& so) {
+  owner.clear();
+  top_owner.clear();
+  if (opt.nranks <= 1) return;
+  assign_owners(S, opt.nranks, owner);
+  so.node_owner = owner.data();
+  so.rank = opt.rank;
+  so.nranks = opt.nranks;
+  int dist = opt.dist_top;
+  if (const char* e = std::getenv("SPLLT_DIST_TOP"))
+    if (*e) dist = std::atoi(e);
+  if (dist < 0) dist = distribute_top_tree(S, owner, opt.nranks) ? 1 : 0;
+  if (dist) {
+    assign_top_owners(S, owner, opt.nranks, top_owner);
+    so.top_owner = top_owner.data();
+  }
+}
+
 Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     : S_(std::move(S)), opt_(opt) {
   int ndev = 0;
@@ -68,15 +87,9 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     so.zones = opt_.zones != 0;
   }
   if (opt_.nranks > 1) {
-    assign_owners(*S_, opt_.nranks, owner_);
-    so.node_owner = owner_.data();
-    so.rank = opt_.rank;
-    so.nranks = opt_.nranks;
+    partition_options(*S_, opt_, owner_, top_owner_, so);
     for (int b = 0; b < S_->nbcol(); ++b)
-      if (owner_[S_->bcols[b].node] < 0) {
-        top_bcols_.push_back(b);
-        xchg_elems_ += (int64_t)S_->bcols[b].nrow * S_->bcols[b].width;
-      }
+      if (owner_[S_->bcols[b].node] < 0) top_bcols_.push_back(b);
     // only the block columns this rank touches (its own branches + the top tree) are cleared
     // per factorization: the others are never read or written here
     for (int b = 0; b < S_->nbcol(); ++b) {
@@ -90,8 +103,6 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     }
   }
   build_program(*S_, so, prog_);
-  for (size_t i = 0; i < prog_.launches.size(); ++i)
-    if (prog_.launches[i].kind == L_EXCHANGE) xchg_idx_ = (int)i;
   upload();
 }
 
@@ -280,28 +291,58 @@ int Engine::enqueue_program() {
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
   launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
   stats_.launches = (int)prog_.launches.size() + 1;
-  if (xchg_idx_ < 0) {
-    int rc = enqueue_range(0, prog_.launches.size());
+  if (!prog_.exchanges.empty() && !xbuf_) return fail(-10, "exchange buffer not set", hipSuccess);
+  return run_from(0);
+}
+
+// Launches [first, ...) until the next exchange point (packed, awaiting_exchange_) or the end.
+int Engine::run_from(size_t first) {
+  for (size_t i = first; i < prog_.launches.size(); ++i) {
+    const Launch& l = prog_.launches[i];
+    if (l.kind == L_EXCHANGE) {
+      int rc = pre_exchange(l);
+      if (rc) return rc;
+      cur_x_ = i;
+      awaiting_exchange_ = true;
+      return 0;
+    }
+    int rc = enqueue_launch(l, false);
     if (rc) return rc;
-    return finish_enqueue();
   }
-  // partitioned: own subtrees, then pack the top-tree block columns
-  if (!xbuf_) return fail(-10, "exchange buffer not set", hipSuccess);
-  int rc = enqueue_range(0, (size_t)xchg_idx_);
-  if (rc) return rc;
-  const Launch& X = prog_.launches[xchg_idx_];
+  awaiting_exchange_ = false;
+  return finish_enqueue();
+}
+
+// The part of an exchange in front of the collective: its dependencies, then what this rank
+// contributes goes into the exchange buffer (all on the chain stream, where the caller then
+// enqueues the collective).
+int Engine::pre_exchange(const Launch& X) {
+  const Exchange& E = prog_.exchanges[(size_t)X.first];
   for (int w : X.wait)
     if (w >= 0) HIPCHK(hipStreamWaitEvent(stream_, dag_events_[w], 0), "exchange wait");
-  int64_t xo = 0;
-  for (int b : top_bcols_) {
-    const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
-    HIPCHK(hipMemcpyAsync(xbuf_ + xo, d_L_ + S.bcols[b].off, sizeof(double) * (size_t)cnt,
-                          hipMemcpyDeviceToDevice, stream_), "pack top tree");
-    xo += cnt;
+  for (int i = E.first_item; i < E.first_item + E.nitems; ++i) {
+    const ExchangeItem& it = prog_.xitems[(size_t)i];
+    if (E.kind == X_BCAST && it.root != opt_.rank) continue;   // the owner sends
+    HIPCHK(hipMemcpyAsync(xbuf_ + it.xoff, (it.space ? d_dinv_ : d_L_) + it.off, sizeof(double) * (size_t)it.count,
+                          hipMemcpyDeviceToDevice, stream_), "pack exchange");
   }
-  launch_flag_pack(stream_, d_flag_, xbuf_ + xo);
+  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_pack(stream_, d_flag_, xbuf_ + (E.elems - 1));
   HIPCHK(hipGetLastError(), "kernel launch");
-  awaiting_exchange_ = true;
+  return 0;
+}
+
+// ... and behind it: what this rank needs comes out of the buffer, the exchange's event fires.
+int Engine::post_exchange(const Launch& X) {
+  const Exchange& E = prog_.exchanges[(size_t)X.first];
+  for (int i = E.first_item; i < E.first_item + E.nitems; ++i) {
+    const ExchangeItem& it = prog_.xitems[(size_t)i];
+    if (E.kind == X_BCAST && it.root == opt_.rank) continue;          // already here
+    if (E.kind == X_REDUCE_OWNER && it.root != opt_.rank) continue;   // somebody else's sum
+    HIPCHK(hipMemcpyAsync((it.space ? d_dinv_ : d_L_) + it.off, xbuf_ + it.xoff, sizeof(double) * (size_t)it.count,
+                          hipMemcpyDeviceToDevice, stream_), "unpack exchange");
+  }
+  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_unpack(stream_, xbuf_ + (E.elems - 1), d_flag_);
+  if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], stream_), "exchange record");
   return 0;
 }
 
@@ -314,24 +355,12 @@ int Engine::sync_phase() {
 int Engine::continue_after_exchange() {
   if (status_) return status_;
   if (!awaiting_exchange_) return -10;
-  const Symbolic& S = *S_;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
-  int64_t xo = 0;
-  for (int b : top_bcols_) {
-    const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
-    HIPCHK(hipMemcpyAsync(d_L_ + S.bcols[b].off, xbuf_ + xo, sizeof(double) * (size_t)cnt,
-                          hipMemcpyDeviceToDevice, stream_), "unpack top tree");
-    xo += cnt;
-  }
-  launch_flag_unpack(stream_, xbuf_ + xo, d_flag_);
-  const Launch& X = prog_.launches[xchg_idx_];
-  if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], stream_), "exchange record");
-  int rc = enqueue_range((size_t)xchg_idx_ + 1, prog_.launches.size());
+  int rc = post_exchange(prog_.launches[cur_x_]);
   if (rc) return rc;
-  rc = finish_enqueue();
+  rc = run_from(cur_x_ + 1);
   if (rc) return rc;
-  HIPCHK(hipEventRecord(ev1_, stream_), "event");
-  awaiting_exchange_ = false;
+  if (!awaiting_exchange_) HIPCHK(hipEventRecord(ev1_, stream_), "event");
   return 0;
 }
 
@@ -477,7 +506,7 @@ int Engine::solve(double* x_host, int nrhs, int job) {
 int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms, bool serial) {
   if (status_) return status_;
   if (nnz != S_->nnzA) return -10;
-  if (xchg_idx_ >= 0) return -98;   // single-GPU programs only
+  if (!prog_.exchanges.empty()) return -98;   // single-GPU programs only
   const Symbolic& S = *S_;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipMemcpy(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice), "val H2D");

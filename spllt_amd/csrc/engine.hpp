@@ -23,6 +23,8 @@ struct EngineOptions {
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
   bool deterministic = false;  // see ScheduleOptions
   bool fused_panel = true;     // see ScheduleOptions
+  int dist_top = -1;           // multi-GPU top tree: 1 distributed over the ranks, 0 replicated on every
+                               // rank, -1 by distribute_top_tree() (env SPLLT_DIST_TOP overrides)
   bool poison_lds = false; // debug: poison the LDS of every CU before every launch
   int reserve_cus = -1;    // CUs the bulk / far streams are masked off (0: no mask; -1: 32 when the
                            // problem is latency-bound (schedule.hpp), else 0)
@@ -36,6 +38,11 @@ struct FactorStats {
   double h2d_ms = 0;
   int launches = 0;
 };
+
+// Partition of the tree for opt.nranks ranks: node owners, and (distributed top tree) the owners of
+// the top-tree block columns; fills the partition fields of so (the vectors must outlive it).
+void partition_options(const Symbolic& S, const EngineOptions& opt, std::vector<int>& owner,
+                       std::vector<int>& top_owner, ScheduleOptions& so);
 
 class Engine {
  public:
@@ -58,11 +65,12 @@ class Engine {
   // subtrees with the top-tree block columns packed into the exchange buffer;
   // the caller reduces that buffer across ranks (RCCL all-reduce), then calls
   // continue_after_exchange() and finally wait().
-  // doubles of the exchange buffer: the top-tree block columns + one element that carries the
-  // "not positive definite" indicator across the ranks
-  int64_t exchange_elems() const { return xchg_elems_ + 1; }
+  // doubles the exchange buffer must hold (the largest exchange of the program)
+  int64_t exchange_elems() const { return prog_.xbuf_elems; }
   int set_exchange_buffer(double* dev_ptr) { xbuf_ = dev_ptr; return 0; }
   bool awaiting_exchange() const { return awaiting_exchange_; }
+  // index (into program().exchanges) of the exchange the engine is waiting for, -1: none
+  int pending_exchange() const { return awaiting_exchange_ ? (int)prog_.launches[cur_x_].first : -1; }
   int sync_phase();                 // drain the streams at the exchange point
   int continue_after_exchange();
   const std::vector<int>& owners() const { return owner_; }
@@ -89,6 +97,9 @@ class Engine {
   int upload();
   int enqueue_program();
   int enqueue_range(size_t first, size_t last);
+  int run_from(size_t first);                 // enqueue launches until the next exchange or the end
+  int pre_exchange(const Launch& X);          // waits + pack
+  int post_exchange(const Launch& X);         // unpack + record
   int finish_enqueue();
   int enqueue_launch(const Launch& l, bool serial);
   int fail(int code, const char* what, hipError_t e);
@@ -112,8 +123,8 @@ class Engine {
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
   bool pending_ = false;
   bool awaiting_exchange_ = false;
-  int xchg_idx_ = -1;               // index of the L_EXCHANGE launch, -1 = single GPU
-  int64_t xchg_elems_ = 0;
+  size_t cur_x_ = 0;                // launch index of the exchange the engine waits for
+  std::vector<int> top_owner_;      // per block column: owner in a distributed top tree (else empty)
   double* xbuf_ = nullptr;          // caller-owned device buffer of xchg_elems_ doubles
   std::vector<int> owner_;          // per node: owning rank or -1 (top tree)
   std::vector<int> top_bcols_;      // block columns of the top tree, in order

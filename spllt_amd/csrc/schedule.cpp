@@ -160,6 +160,11 @@ struct Builder {
 
   // Inter-node update units of node s, one per touched ancestor block column,
   // covering every K segment (block column) of s.
+  // dist2 (phase 2 of a program with a distributed top tree): only the destination block columns
+  // this rank owns
+  bool dist2 = false;
+  bool mine(int b) const { return !dist2 || opt.top_owner[b] == opt.rank; }
+
   void between_templates(int s, std::vector<UpdUnit>& out) {
     const int nn = S.nnodes;
     const int m = S.nrow(s);
@@ -214,7 +219,7 @@ struct Builder {
           u.k0 = 0;
           u.klen = -1;
           u.dinv_ld = S.node_bcol0[a] + cb;   // (unused by the kernel in this mode) destination block column
-          out.push_back(u);
+          if (mine(u.dinv_ld)) out.push_back(u);
           cptr = cptr2 + 1;
         }
       }
@@ -420,11 +425,49 @@ struct Builder {
       if (partitioned) take = (ph == 0) ? (opt.node_owner[s] == opt.rank) : (opt.node_owner[s] < 0);
       if (take) by_level[S.level[s]].push_back(s);
     }
+    dist2 = partitioned && ph == 1 && opt.top_owner != nullptr;
     if (partitioned && ph == 1) {
+      // extend-add of the top-tree block columns across the ranks
+      Exchange E{};
+      E.first_item = (int)P.xitems.size();
+      std::vector<int> top;
+      for (int b = 0; b < S.nbcol(); ++b)
+        if (opt.node_owner[S.bcols[b].node] < 0) top.push_back(b);
+      if (!dist2) {
+        E.kind = X_REDUCE_ALL;
+        int64_t o = 0;
+        for (int b : top) {
+          const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+          P.xitems.push_back(ExchangeItem{b, -1, o, cnt, S.bcols[b].off, 0});
+          o += cnt;
+        }
+        E.elems = o + 1;   // + the "not positive definite" indicator
+        E.chunk = 0;
+      } else {
+        E.kind = X_REDUCE_OWNER;
+        std::vector<int64_t> fill((size_t)opt.nranks, 0);
+        for (int b : top) fill[(size_t)opt.top_owner[b]] += (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+        int64_t chunk = 1;
+        for (int64_t v : fill) chunk = std::max(chunk, v);
+        std::fill(fill.begin(), fill.end(), 0);
+        for (int r = 0; r < opt.nranks; ++r)
+          for (int b : top) {
+            if (opt.top_owner[b] != r) continue;
+            const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+            P.xitems.push_back(ExchangeItem{b, r, (int64_t)r * chunk + fill[(size_t)r], cnt, S.bcols[b].off, 0});
+            fill[(size_t)r] += cnt;
+          }
+        E.chunk = chunk;
+        E.elems = chunk * opt.nranks;
+      }
+      E.nitems = (int)P.xitems.size() - E.first_item;
+      P.xbuf_elems = std::max(P.xbuf_elems, E.elems);
       Launch X;
       X.kind = L_EXCHANGE;
       X.level = -1;
-      X.first = X.count = 0;
+      X.first = (int64_t)P.exchanges.size();
+      X.count = 0;
+      P.exchanges.push_back(E);
       X.tile = 0;
       X.flops = 0;
       X.stream = ST_CHAIN;
@@ -477,6 +520,7 @@ struct Builder {
           for (int s : nodes) {
             const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
             if (c >= nc) continue;
+            if (!mine(S.node_bcol0[s] + c)) continue;
             const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
             nt += std::max(1, cdiv(B.nrow - std::min(pw, B.width), 64));
           }
@@ -507,6 +551,7 @@ struct Builder {
               const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
               if (c >= nc) continue;
               const int b = S.node_bcol0[s] + c;
+              if (!mine(b)) continue;
               const BlockCol& B = S.bcols[b];
               const int c0 = cs;
               if (c0 >= B.width) continue;
@@ -556,6 +601,7 @@ struct Builder {
                 const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
                 if (c >= nc) continue;
                 const int b = S.node_bcol0[s] + c;
+                if (!mine(b)) continue;
                 const BlockCol& B = S.bcols[b];
                 const int c0 = cs + q * pw;
                 if (c0 >= std::min(B.width, cs + cb)) continue;
@@ -606,6 +652,7 @@ struct Builder {
                 const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
                 if (c >= nc) continue;
                 const int b = S.node_bcol0[s] + c;
+                if (!mine(b)) continue;
                 const BlockCol& B = S.bcols[b];
                 const int c0 = cs + q * pw;
                 if (c0 >= std::min(B.width, cs + cb)) continue;
@@ -631,6 +678,7 @@ struct Builder {
               const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
               if (c >= nc) continue;
               const int b = S.node_bcol0[s] + c;
+              if (!mine(b)) continue;
               const BlockCol& B = S.bcols[b];
               const int c0 = cs + q * pw;
               if (c0 >= std::min(B.width, cs + cb)) continue;
@@ -679,6 +727,50 @@ struct Builder {
             P.launches.push_back(M);
             evD_last = evD;
           }
+          // (3b) distributed top tree: the block columns that are final with this chunk go from
+          // their owners to everybody (the exchange sits on the chain stream: whatever reads
+          // them waits for its event)
+          if (dist2) {
+            Exchange E{};
+            E.kind = X_BCAST;
+            E.first_item = (int)P.xitems.size();
+            int64_t o = 0;
+            for (int r = 0; r < opt.nranks; ++r)
+              for (int s : nodes) {
+                const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+                if (c >= nc) continue;
+                const int b = S.node_bcol0[s] + c;
+                const BlockCol& B = S.bcols[b];
+                if (opt.top_owner[b] != r || cs >= B.width || cs + cb < B.width) continue;
+                const int64_t cnt = (int64_t)B.nrow * B.width;
+                P.xitems.push_back(ExchangeItem{b, r, o, cnt, B.off, 0});
+                o += cnt;
+                const int64_t dcnt = dinv_slot[b + 1] - dinv_slot[b];
+                P.xitems.push_back(ExchangeItem{b, r, o, dcnt, dinv_slot[b], 1});
+                o += dcnt;
+              }
+            E.nitems = (int)P.xitems.size() - E.first_item;
+            E.elems = o;
+            if (E.nitems > 0) {
+              P.xbuf_elems = std::max(P.xbuf_elems, E.elems);
+              Launch X;
+              X.kind = L_EXCHANGE;
+              X.level = lev;
+              X.first = (int64_t)P.exchanges.size();
+              X.count = 0;
+              X.tile = 0;
+              X.flops = 0;
+              X.stream = ST_CHAIN;
+              P.exchanges.push_back(E);
+              if (la) {
+                X.add_wait(evD);
+                evD = P.nevents++;      // "block column final AND here"
+                X.record = evD;
+                evD_last = evD;
+              }
+              P.launches.push_back(X);
+            }
+          }
           // (4) updates by the finished chunk, left-looking inside the block column: the next
           // chunk's columns by everything left of them (chain stream: small launches that fit
           // the reserved CUs).  After the last chunk the whole block column updates block
@@ -694,7 +786,7 @@ struct Builder {
             if (cs >= B.width) continue;
             const int ce = std::min(B.width, cs + cb);
             if (ce < B.width) {
-              if (fuse_c) continue;   // part of the panel launch
+              if (fuse_c || !mine(b)) continue;   // part of the panel launch / the owner's business
               const int ce2 = std::min(B.width, ce + cb);
               UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
               us_n1.push_back(n1);
@@ -703,6 +795,7 @@ struct Builder {
               // last chunk: the whole block column updates the node's later block columns
               for (int jj = c + 1; jj < nc; ++jj) {
                 const int bd = S.node_bcol0[s] + jj;
+                if (!mine(bd)) continue;
                 const BlockCol& D = S.bcols[bd];
                 if (jj == c + 1) {
                   to_next_bcol = true;
@@ -835,6 +928,28 @@ struct Builder {
       }
     }
     }  // phases
+    if (partitioned && opt.top_owner != nullptr) {
+      // a failed pivot anywhere: every rank learns it at the end
+      Exchange E{};
+      E.kind = X_FLAG;
+      E.first_item = (int)P.xitems.size();
+      E.nitems = 0;
+      E.elems = 1;
+      P.xbuf_elems = std::max<int64_t>(P.xbuf_elems, 1);
+      Launch X;
+      X.kind = L_EXCHANGE;
+      X.level = -1;
+      X.first = (int64_t)P.exchanges.size();
+      X.count = 0;
+      X.tile = 0;
+      X.flops = 0;
+      X.stream = ST_CHAIN;
+      P.exchanges.push_back(E);
+      X.add_wait(ev_level);
+      ev_level = P.nevents++;
+      X.record = ev_level;
+      P.launches.push_back(X);
+    }
     P.final_event = ev_level;
   }
 };
@@ -850,6 +965,42 @@ bool latency_bound(const Symbolic& S, int pw) {
   for (int w : widest) chain_us += 60.0 * ((w + pw - 1) / pw);
   const double bulk_us = (double)S.flops / 45e6;   // 45 TFLOP/s
   return chain_us > 0.25 * bulk_us;
+}
+
+void assign_top_owners(const Symbolic& S, const std::vector<int>& node_owner, int nranks,
+                       std::vector<int>& top_owner) {
+  top_owner.assign((size_t)S.nbcol(), -1);
+  if (nranks < 1) nranks = 1;
+  int maxlevel = -1;
+  for (int s = 0; s < S.nnodes; ++s) maxlevel = std::max(maxlevel, S.level[s]);
+  std::vector<std::vector<int>> by_level((size_t)maxlevel + 1);
+  for (int s = 0; s < S.nnodes; ++s)
+    if (node_owner[(size_t)s] < 0) by_level[(size_t)S.level[s]].push_back(s);
+  int next = 0;
+  for (const auto& nodes : by_level) {
+    int maxnc = 0;
+    for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
+    for (int c = 0; c < maxnc; ++c)
+      for (int s : nodes)
+        if (c < S.node_bcol0[s + 1] - S.node_bcol0[s]) top_owner[(size_t)(S.node_bcol0[s] + c)] = next++ % nranks;
+  }
+}
+
+bool distribute_top_tree(const Symbolic& S, const std::vector<int>& node_owner, int nranks) {
+  if (nranks < 2) return false;
+  // flops of the top tree (the reference's symbolic count per node, spllt_analyse_mod:1007-1023)
+  double top_flops = 0;
+  int64_t steps = 0;
+  for (int s = 0; s < S.nnodes; ++s) {
+    if (node_owner[(size_t)s] >= 0) continue;
+    const double m = S.nrow(s), n = S.ncol(s);
+    for (int j = 1; j <= (int)n; ++j) top_flops += (m - n + j) * (m - n + j);
+    steps += S.node_bcol0[s + 1] - S.node_bcol0[s];
+  }
+  // replicated: every rank spends top_flops / rate; distributed: 1 / nranks of that, plus one
+  // broadcast (launch + hand-over, ~60 us) per block column step
+  const double saved_us = top_flops * (1.0 - 1.0 / nranks) / 45e6;   // 45 TFLOP/s
+  return saved_us > 60.0 * (double)steps;
 }
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {

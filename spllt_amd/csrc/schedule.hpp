@@ -163,6 +163,34 @@ struct Launch {
   }
 };
 
+// Points of a partitioned (multi-GPU) program where the ranks exchange block columns of the top
+// tree through the exchange buffer (host: a collective on the engine's stream between the pack and
+// the unpack).  Every rank's program has the same exchanges in the same order.
+enum ExchangeKind : int {
+  X_REDUCE_ALL = 0,    // all-reduce(sum) of every top-tree block column + one indicator element
+                       // (replicated top tree: everybody continues with the whole sum)
+  X_REDUCE_OWNER = 1,  // reduce-scatter(sum): rank r's chunk [r*chunk, (r+1)*chunk) holds the block
+                       // columns r owns (distributed top tree)
+  X_BCAST = 2,         // the owners broadcast the block columns of a finished step (one segment of
+                       // the buffer per root, items of a root contiguous)
+  X_FLAG = 3           // all-reduce(sum) of the one-element "not positive definite" indicator
+};
+struct ExchangeItem {
+  int bcol;
+  int root;        // owner (X_REDUCE_ALL: -1)
+  int64_t xoff;    // offset in the exchange buffer
+  int64_t count;   // doubles: nrow * width (space 0), the block column's dinv slots (space 1)
+  int64_t off;     // offset in the arena (space 0) / the dinv scratch (space 1)
+  int space;       // 0: arena; 1: dinv scratch -- a broadcast block column travels with the
+                   // inverses of its diagonal panels, which the solve needs on every rank
+};
+struct Exchange {
+  int kind;
+  int first_item, nitems;   // range in xitems
+  int64_t elems;            // doubles of the buffer the collective covers (from offset 0)
+  int64_t chunk;            // X_REDUCE_OWNER: elems / nranks
+};
+
 struct Program {
   int pw = 64;  // inner panel width
   int cb = 64;  // chain block: edge of the diagonal sub-tiles the chain kernels walk
@@ -177,6 +205,10 @@ struct Program {
   std::vector<Launch> launches;
   std::vector<int> relpos;      // per (node, touched ancestor): positions of the node's rows in the ancestor's row list
   int64_t dinv_size = 0;        // doubles
+  // L_EXCHANGE launches (multi-GPU): Launch::first = index into exchanges
+  std::vector<Exchange> exchanges;
+  std::vector<ExchangeItem> xitems;
+  int64_t xbuf_elems = 0;       // size the exchange buffer must have (doubles)
   int nevents = 0;              // number of distinct event ids used by the launches
   int final_event = -1;         // recorded when everything is done
   double flops_potrf = 0, flops_trsm = 0, flops_update = 0, flops_between = 0;
@@ -192,6 +224,12 @@ struct ScheduleOptions {
   int rank = 0;
   int nranks = 1;
   const int* node_owner = nullptr;
+  // distributed top tree: top_owner[b] = rank that owns block column b of the
+  // top tree (-1 elsewhere).  The extend-add at the exchange point goes to the owners only
+  // (X_REDUCE_OWNER); in the top tree a block column is factorized by its owner, broadcast
+  // (X_BCAST), and every rank applies it to the destination block columns it owns.  null: the top
+  // tree is replicated (X_REDUCE_ALL, every rank factorizes all of it).
+  const int* top_owner = nullptr;
   bool lookahead = true;  // multi-stream schedule: the chain of block column c+1 overlaps the
                           // trailing update by block column c; false: one stream, program order
   bool slice_between = true;  // (lookahead) inter-node updates are issued in K slices on the far
@@ -221,6 +259,16 @@ inline int64_t winv_offset(int w, int pw, int cb, int p) {
 }
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);
+
+// owners of the top-tree block columns of a partition (node_owner from assign_owners): dealt
+// round-robin in the order the top tree is walked (level, step, node), so that the block columns
+// of one step - whose panel chains can run at the same time - sit on different ranks, and the
+// block columns of a node are spread 1-D cyclically.  -1 for block columns outside the top tree.
+void assign_top_owners(const Symbolic& S, const std::vector<int>& node_owner, int nranks,
+                       std::vector<int>& top_owner);
+// Is a distributed top tree worth its broadcasts?  (flops the replicated top tree repeats on
+// every rank against the latency the per-step broadcasts add)
+bool distribute_top_tree(const Symbolic& S, const std::vector<int>& node_owner, int nranks);
 
 // Is the factorization of S bound by the latency of its panel chains rather than by matrix
 // throughput?  Estimate: the longest chain of dependent panel steps through the tree (one step

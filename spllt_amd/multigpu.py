@@ -31,62 +31,124 @@ def reduce_exchange_buffer(xbuf, group=None):
     return xbuf
 
 
+X_REDUCE_ALL, X_REDUCE_OWNER, X_BCAST, X_FLAG = 0, 1, 2, 3
+
+
+def exchange_plan(f):
+    """Per exchange of f's program (include/spllt_hip.h, spllt_hip_set_partition):
+    (kind, elems, chunk, segments) with segments = [(root, offset, length)] of an X_BCAST."""
+    plan = []
+    items = f.program("xitems")
+    for kind, first, n, elems, chunk in f.program("exchanges").tolist():
+        segs = []
+        if kind == X_BCAST:
+            for b, root, xo, cnt, _off, _space in items[first:first + n].tolist():
+                if segs and segs[-1][0] == root and segs[-1][1] + segs[-1][2] == xo:
+                    segs[-1][2] += cnt
+                else:
+                    segs.append([root, xo, cnt])
+        plan.append((kind, elems, chunk, [tuple(s) for s in segs]))
+    return plan
+
+
+def run_exchange(xbuf, step, rank, world, group=None, scratch=None):
+    """The collective of one exchange on the (torch) exchange buffer, in place; enqueue-only on
+    RCCL.  step = one entry of exchange_plan().  X_REDUCE_OWNER leaves rank r's sum at
+    xbuf[r*chunk:(r+1)*chunk] (gloo has no reduce-scatter: an all-reduce does the same there)."""
+    import torch.distributed as dist
+    kind, elems, chunk, segs = step
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return xbuf
+    if kind in (X_REDUCE_ALL, X_FLAG):
+        dist.all_reduce(xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
+    elif kind == X_REDUCE_OWNER:
+        if dist.get_backend(group) == "nccl":
+            out = scratch[:chunk] if scratch is not None else xbuf.new_empty(chunk)
+            dist.reduce_scatter_tensor(out, xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
+            xbuf[rank * chunk:(rank + 1) * chunk].copy_(out)
+        else:
+            dist.all_reduce(xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
+    elif kind == X_BCAST:
+        for root, off, cnt in segs:
+            src = dist.get_global_rank(group, root) if group is not None else root
+            dist.broadcast(xbuf[off:off + cnt], src=src, group=group)
+    return xbuf
+
+
 class DistributedFactorization:
     """Factorization of one pattern on `world` GPUs (this process = `rank` of
-    the process group `group`).  world == 1 is the plain single-GPU engine."""
+    the process group `group`).  world == 1 is the plain single-GPU engine.
+    dist_top: None = the engine decides (weight of the top tree), True / False = top tree
+    distributed over the ranks / replicated on every rank."""
 
     def __init__(self, n, ptr, row, nb, rank, world, order=None, nemin=32, panel_width=None,
-                 group=None):
+                 group=None, dist_top=None, engine_flags=0):
         import torch
         import torch.distributed as dist
         from . import api
         self.rank, self.world, self.group = rank, world, group
+        if dist_top is not None:
+            engine_flags |= 8192 if dist_top else 16384
         self.f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=world > 1,
-                                   ncpu=world, order=order, panel_width=panel_width)
+                                   ncpu=world, order=order, panel_width=panel_width,
+                                   engine_flags=engine_flags)
         self.xelems = self.f.set_partition(rank, world) if world > 1 else 0
         self.xbuf = torch.zeros(max(self.xelems, 1), dtype=torch.float64, device="cuda")
         self.ext = None
+        self.plan, self.scratch = [], None
         if world > 1:
             self.f.set_exchange_buffer(self.xbuf.data_ptr())
             # the engine's own stream as a torch stream: collectives enqueued under it are
             # ordered behind the pack and in front of the unpack without a host round trip
             self.ext = torch.cuda.ExternalStream(self.f.engine_stream())
+            self.plan = exchange_plan(self.f)
+            chunk = max([st[2] for st in self.plan] + [0])
+            if chunk:
+                self.scratch = torch.empty(chunk, dtype=torch.float64, device="cuda")
+        self.dist_top = any(st[0] == X_REDUCE_OWNER for st in self.plan)
         self.stream_ordered = (world > 1 and dist.is_initialized() and
                                (dist.get_backend(group) == "nccl" or
                                 bool(os.environ.get("SPLLT_FORCE_STREAM_ORDERED"))))   # (tests: gloo)
         self.phase_ms = {}
 
-    def _exchange(self):
-        """extend-add of the top-tree block columns (+ the not-positive-definite
-        indicator): one all-reduce(sum) on the engine's stream"""
+    def _exchange(self, k):
+        """exchange k of the program: the collective on the engine's stream, between the
+        engine's pack and unpack"""
         import torch
+        step = self.plan[k]
         if self.stream_ordered:
             with torch.cuda.stream(self.ext):
-                reduce_exchange_buffer(self.xbuf, self.group)   # RCCL: enqueue only
+                run_exchange(self.xbuf, step, self.rank, self.world, self.group, self.scratch)   # RCCL: enqueue only
         else:
             # gloo (CPU tests / one-GPU rehearsal) stages through the host: plain syncs
             self.ext.synchronize()
-            reduce_exchange_buffer(self.xbuf, self.group)
+            run_exchange(self.xbuf, step, self.rank, self.world, self.group, self.scratch)
             torch.cuda.synchronize()
 
     def factor(self, dval, timed_phases=False):
-        """One complete distributed factorization (dval: cuda float64 tensor).  The three
-        phases -- own subtrees, exchange, top tree -- are enqueued back to back on the
-        engine's stream; the host only waits at the end (timed_phases=True adds a host
-        synchronisation after each phase to time it).  A pivot failure on any rank raises
-        the same SplltError(-20) on every rank after the last phase."""
+        """One complete distributed factorization (dval: cuda float64 tensor).  The phases
+        -- own subtrees, extend-add, top tree (with its broadcasts when it is distributed) --
+        are enqueued back to back on the engine's stream; the host only waits at the end
+        (timed_phases=True adds a host synchronisation around the first exchange to time the
+        phases).  A pivot failure on any rank raises the same SplltError(-20) on every rank
+        after the last phase."""
         t0 = time.perf_counter()
         self.f.factor_dev(dval.data_ptr())
         t1 = t2 = t0
-        if self.world > 1:
-            if timed_phases:
+        nx = 0
+        while True:
+            k = self.f.pending_exchange()
+            if k < 0:
+                break
+            if timed_phases and nx == 0:
                 self.ext.synchronize()
                 t1 = time.perf_counter()
-            self._exchange()
-            if timed_phases:
+            self._exchange(k)
+            if timed_phases and nx == 0:
                 self.ext.synchronize()
                 t2 = time.perf_counter()
             self.f.continue_after_exchange()
+            nx += 1
         self.f.wait()
         t3 = time.perf_counter()
         if timed_phases or self.world == 1:
@@ -227,10 +289,14 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "n": n, "nb": nb, "nnz_L": int(si_t[1].item()),
                        "flops_sym": flops, "nnodes": int(si_t[2].item()),
-                       "parallelism": f"subtree partition over all {world} GPUs + one RCCL all-reduce "
-                                      "(extend-add) on the engine's stream, replicated top tree"},
+                       "parallelism": (f"subtree partition over all {world} GPUs + RCCL reduce-scatter (extend-add) "
+                                       "to the owners of a 1-D block-column-cyclic top tree, one broadcast "
+                                       "per finished block-column step" if df.dist_top else
+                                       f"subtree partition over all {world} GPUs + one RCCL all-reduce "
+                                       "(extend-add) on the engine's stream, replicated top tree")},
             "roofline": None, "cpu_baseline": None,
-            "detail": {"partition_width": w, "width_trials_ms": trial,
+            "detail": {"partition_width": w, "width_trials_ms": trial, "distributed_top_tree": df.dist_top,
+                       "exchanges": len(df.plan),
                        "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
                        "subtree_gflop_per_rank": (own_w / 1e9).round(1).tolist(),
                        "top_tree_gflop": round(top_flops / 1e9, 1), "check": check,

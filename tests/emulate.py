@@ -10,8 +10,9 @@ MODE_DIRECT, MODE_SCATTER, MODE_TRSM = 0, 1, 2
 
 
 def emulate_program(f, val, exchange=None, partitioned=False):
-    """exchange(xbuf) -> summed xbuf is called at the EXCHANGE marker of a
-    partitioned (multi-GPU) program with the packed top-tree block columns."""
+    """exchange(k, xbuf) -> xbuf after the collective is called at every EXCHANGE launch of a
+    partitioned (multi-GPU) program: k = index into f.program("exchanges"), xbuf = this rank's
+    packed exchange buffer (spllt_amd.multigpu.run_exchange is the production collective)."""
     info = f.sym_info()
     arena = np.zeros(info["arena"])
     md, ms = f.sym("map_dst"), f.sym("map_src")
@@ -49,18 +50,21 @@ def emulate_program(f, val, exchange=None, partitioned=False):
 
     bc_nrow = f.sym("bcol_nrow")
     for kind, level, first, count, tile in launches[:, :5]:
-        if kind == 2:  # EXCHANGE: pack the top-tree block columns, reduce, unpack
-            top = f.partition("top_bcols")
-            sl_ = [slice(int(bc_off[b]), int(bc_off[b]) + int(bc_nrow[b]) * int(bc_w[b]))
-                   for b in top]
-            # + one element: the "not positive definite" indicator (0 = this rank is fine)
-            xbuf = np.concatenate([arena[s_] for s_ in sl_] + [np.zeros(1)])
-            xbuf = exchange(xbuf)
-            o = 0
-            for s_ in sl_:
-                k = s_.stop - s_.start
-                arena[s_] = xbuf[o:o + k]
-                o += k
+        if kind == 2:  # EXCHANGE k: pack, the caller's collective, unpack (engine.cpp pre_/post_exchange)
+            xk, xfirst, xn, xelems, xchunk = (int(v) for v in f.program("exchanges")[first])
+            items = f.program("xitems")[xfirst:xfirst + xn]
+            rank = getattr(f, "rank", 0)
+            xbuf = np.zeros(max(1, f.program("xbuf_elems")))
+            for b, root, xo, cnt, off, space in items:
+                if xk == 2 and root != rank:
+                    continue                      # the owner sends
+                xbuf[xo:xo + cnt] = (dinv if space else arena)[off:off + cnt]
+            # kinds 0 and 3: the last element is the "not positive definite" indicator (0 = fine)
+            xbuf = exchange(first, xbuf)
+            for b, root, xo, cnt, off, space in items:
+                if (xk == 2 and root == rank) or (xk == 1 and root != rank):
+                    continue
+                (dinv if space else arena)[off:off + cnt] = xbuf[xo:xo + cnt]
             continue
         if kind == 4:  # one step of the panel chain per unit (k_chain_panel)
             for q in f.program("chains")[first:first + count]:
@@ -250,3 +254,66 @@ def emulate_solve(f, arena, y, job=0, phase=-1):
     if do_b and phase in (-1, 2):
         run(bwd[ntop:])
     return y
+
+
+class LockstepExchange:
+    """The collectives of a partitioned program for `world` emulated (or single-device) ranks
+    that run in threads of this process: rank r calls ex.callback(r)(k, xbuf) at its exchange k,
+    all ranks meet there, and everybody gets back what the collective of
+    spllt_amd.multigpu.run_exchange would leave in its buffer.  Strict: the parts of a buffer a
+    rank has no right to read afterwards (other ranks' chunks of a reduce-scatter, anything
+    outside the broadcast segments) come back as NaN."""
+
+    def __init__(self, world, plan):
+        import threading
+        self.world, self.plan = world, plan
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.out = [None] * world
+
+    def _collective(self, k):
+        kind, elems, chunk, segs = self.plan[k]
+        bufs = self.slots
+        for r in range(self.world):
+            res = np.full_like(bufs[r], np.nan)
+            if kind in (0, 3):
+                res[:elems] = np.sum([b[:elems] for b in bufs], axis=0)
+            elif kind == 1:
+                res[r * chunk:(r + 1) * chunk] = np.sum([b[r * chunk:(r + 1) * chunk] for b in bufs], axis=0)
+            else:
+                for root, off, cnt in segs:
+                    res[off:off + cnt] = bufs[root][off:off + cnt]
+            self.out[r] = res
+
+    def callback(self, rank):
+        def exchange(k, xbuf):
+            self.slots[rank] = np.array(xbuf, copy=True)
+            if self.bar.wait() == 0:
+                self._collective(k)
+            self.bar.wait()
+            return self.out[rank]
+        return exchange
+
+
+def emulate_ranks(fs, val):
+    """every rank's program of one partitioned factorization, interpreted in lockstep (one thread
+    per rank); returns the ranks' arenas"""
+    import threading
+    from spllt_amd import multigpu
+    ex = LockstepExchange(len(fs), multigpu.exchange_plan(fs[0]))
+    res, err = [None] * len(fs), []
+
+    def work(r):
+        try:
+            res[r] = emulate_program(fs[r], val, exchange=ex.callback(r), partitioned=True)
+        except BaseException as e:   # noqa: BLE001 - surfaced below; do not leave the others waiting
+            err.append(e)
+            ex.bar.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(len(fs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return res

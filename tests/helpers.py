@@ -73,3 +73,41 @@ def bwd_err(A, x, b):
     ||b - A x||_2 / (||b||_2 + max|a_ij| ||x||_2); pass iff <= 1e-14."""
     r = b - A @ x
     return float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x)))
+
+
+def drive_exchanges(fs, bufs, on_exchange=None):
+    """All exchanges of a partitioned factorization whose rank-engines run in THIS process on
+    one device (fs[r] = rank r, bufs[r] = its torch exchange buffer): every engine has been
+    started (factor_dev); at each exchange point the streams are drained, the collective is
+    done with torch ops (what spllt_amd.multigpu.run_exchange does across devices), and the
+    engines continue.  Strict: what a rank may not read after a collective comes back as NaN.
+    Returns the number of exchanges."""
+    import torch
+    from spllt_amd import multigpu
+    plan = multigpu.exchange_plan(fs[0])
+    world, nx = len(fs), 0
+    while True:
+        ks = [f.pending_exchange() for f in fs]
+        assert len(set(ks)) == 1, ks          # every rank is at the same exchange
+        k = ks[0]
+        if k < 0:
+            return nx
+        for f in fs:
+            f.wait()                           # at an exchange point: drains the streams only
+        kind, elems, chunk, segs = plan[k]
+        src = [b.clone() for b in bufs]
+        if on_exchange:
+            on_exchange(k, kind, src)
+        for r, b in enumerate(bufs):
+            b.fill_(float("nan"))
+            if kind in (0, 3):
+                b[:elems] = torch.stack([s[:elems] for s in src]).sum(dim=0)
+            elif kind == 1:
+                b[r * chunk:(r + 1) * chunk] = torch.stack([s[r * chunk:(r + 1) * chunk] for s in src]).sum(dim=0)
+            else:
+                for root, off, cnt in segs:
+                    b[off:off + cnt] = src[root][off:off + cnt]
+        torch.cuda.synchronize()
+        for f in fs:
+            f.continue_after_exchange()
+        nx += 1

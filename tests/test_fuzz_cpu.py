@@ -9,7 +9,7 @@ import scipy.sparse as sp
 
 from spllt_amd import matgen
 from helpers import dense_arena, lower_mask, make_case, rel_err
-from emulate import emulate_program
+from emulate import emulate_program, emulate_ranks
 import test_schedule as ts
 
 
@@ -61,37 +61,22 @@ def test_fuzz_program_partitioned(seed):
     world = int(rng.integers(2, 5))
     nb = int(rng.choice([8, 16, 32, 48]))
     pw = int(rng.choice([8, 16, 24]))
+    # top tree replicated on every rank / distributed over the ranks (owner computes)
+    flags = int(rng.choice([8192, 16384]))
     fs, vals = [], None
     for r in range(world):
-        f, vals = make_case(A, nb=nb, nemin=8, prune=True, ncpu=world, panel_width=pw)
+        f, vals = make_case(A, nb=nb, nemin=8, prune=True, ncpu=world, panel_width=pw, engine_flags=flags)
         f.set_partition(r, world)
         fs.append(f)
     ref, mask = dense_arena(fs[0], A), lower_mask(fs[0])
-    # two passes: first collect every rank's packed top-tree block columns, then replay
-    # each rank with the summed buffer (what the all-reduce delivers)
-    class _AtExchange(Exception):
-        pass
-
-    packed = []
-    for f in fs:
-        box = {}
-
-        def grab(x, box=box):
-            box["x"] = x.copy()
-            raise _AtExchange()      # phase 1 only: the top tree is not complete yet
-        try:
-            emulate_program(f, vals, exchange=grab, partitioned=True)
-        except _AtExchange:
-            pass
-        packed.append(box.get("x", np.zeros(0)))
-    total = np.sum(packed, axis=0) if len(packed[0]) else packed[0]
     owner, bc_node = fs[0].partition("owner"), fs[0].sym("bcol_node")
     off, w, nr = fs[0].sym("bcol_off"), fs[0].sym("bcol_width"), fs[0].sym("bcol_nrow")
+    arenas = emulate_ranks(fs, vals)     # all ranks in lockstep, numpy collectives
     for r, f in enumerate(fs):
-        got = emulate_program(f, vals, exchange=lambda x: total, partitioned=True)
+        got = arenas[r]
         mine = np.zeros_like(mask)
         for b in range(len(off)):
             if owner[bc_node[b]] in (r, -1):
                 mine[off[b]:off[b] + nr[b] * w[b]] = True
-        assert rel_err(got, ref, mask & mine) < 1e-12, (world, nb, pw, r)
-        assert _dag_is_ordered(f), (world, nb, pw, r)
+        assert rel_err(got, ref, mask & mine) < 1e-12, (world, nb, pw, r, flags)
+        assert _dag_is_ordered(f), (world, nb, pw, r, flags)

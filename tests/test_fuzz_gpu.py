@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import bwd_err, lower_mask, make_case, oracle_factor, rel_err
+from helpers import bwd_err, drive_exchanges, lower_mask, make_case, oracle_factor, rel_err
 from spllt_amd import matgen
 
 pytestmark = pytest.mark.gpu
@@ -70,12 +70,12 @@ def test_ragged_panels_in_every_engine_variant(flags, cb, nb, pw):
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
-def _partitioned_factor_and_solve(A, world, nb, nemin, pw):
+def _partitioned_factor_and_solve(A, world, nb, nemin, pw, flags=0):
     """`world` rank-engines on this device; torch sums stand for the all-reduces."""
     import torch
     fs, bufs = [], []
     for r in range(world):
-        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw)
+        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw, engine_flags=flags)
         xel = f.set_partition(r, world)
         xb = torch.zeros(max(xel, 1), dtype=torch.float64, device="cuda")
         f.set_exchange_buffer(xb.data_ptr())
@@ -84,13 +84,8 @@ def _partitioned_factor_and_solve(A, world, nb, nemin, pw):
     dval = torch.tensor(val, device="cuda")
     for f in fs:
         f.factor_dev(dval.data_ptr())
-        f.wait()
-    total = torch.stack(bufs).sum(dim=0)
-    for xb in bufs:
-        xb.copy_(total)
-    torch.cuda.synchronize()
+    drive_exchanges(fs, bufs)
     for f in fs:
-        f.continue_after_exchange()
         f.wait()
     n = fs[0].n
     owner, sptr, pos = fs[0].partition("owner"), fs[0].sym("sptr"), fs[0].sym("order")
@@ -136,7 +131,8 @@ def test_fuzz_partitioned_factor_and_solve(seed):
     nb = int(rng.choice([8, 16, 32, 48, 100]))
     pw = int(rng.choice([8, 16, 24, 64]))
     nemin = int(rng.choice([4, 16, 32]))
-    fs, val, got, B = _partitioned_factor_and_solve(A, world, nb, nemin, pw)
+    flags = int(rng.choice([8192, 16384]))      # top tree distributed over the ranks / replicated
+    fs, val, got, B = _partitioned_factor_and_solve(A, world, nb, nemin, pw, flags)
     o, rc = oracle_factor(fs[0], val)
     assert rc == 0
     ref, mask = o.arena(), lower_mask(fs[0])

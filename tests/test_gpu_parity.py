@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from helpers import bwd_err, dense_arena, lower_mask, make_case, oracle_factor, rel_err
+from helpers import drive_exchanges, bwd_err, dense_arena, lower_mask, make_case, oracle_factor, rel_err
 from spllt_amd import api, matgen
 
 pytestmark = pytest.mark.gpu
@@ -327,27 +327,35 @@ def test_c_caller_inside_omp_parallel_single():
         assert f"team={threads}" in r.stdout and "fail=0" in r.stdout, r.stdout
 
 
+DIST_TOP = {"replicated": 16384, "distributed": 8192}    # engine flag bits 14 / 13
+
+
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_engine_two_ranks_on_one_gpu(world):
+def test_partitioned_engine_two_ranks_on_one_gpu(world, top):
     """Multi-GPU engine path on the one-GPU box: `world` rank-engines run in
-    this process on the same device; the exchange buffers are summed with a
-    torch add (what RCCL all-reduce does across devices).  Every rank must end
+    this process on the same device; the collectives of the exchanges are done with
+    torch ops (what RCCL does across devices).  Top tree replicated (one all-reduce) or
+    distributed over the ranks (reduce-scatter to the owners, a broadcast per finished
+    block-column step, owner computes).  Every rank must end
     with its own subtrees + the whole top tree equal to the oracle's L."""
-    _run_partitioned(matgen.nd_like((10, 9, 8), 2), 32, 8, world, 16, "plain")
+    _run_partitioned(matgen.nd_like((10, 9, 8), 2), 32, 8, world, 16, "plain", top=top)
 
 
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("name,gen,nb", BIG_CASES)
-def test_config_tile_sizes_partitioned(name, gen, nb, world):
+def test_config_tile_sizes_partitioned(name, gen, nb, world, top):
     """configs 3/4/5 tile sizes through the 2- and 4-rank partition on one device"""
-    _run_partitioned(gen(), nb, 32, world, None, "mkl", check_multicolumn=nb)
+    _run_partitioned(gen(), nb, 32, world, None, "mkl", check_multicolumn=nb, top=top)
 
 
-def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None):
+def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None, top="replicated"):
     torch = _torch()
     fs, bufs = [], []
     for r in range(world):
-        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw)
+        f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw,
+                           engine_flags=DIST_TOP[top])
         if check_multicolumn:
             _assert_multicolumn(f, check_multicolumn)
         xel = f.set_partition(r, world)
@@ -360,14 +368,16 @@ def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None):
     torch.cuda.synchronize()
     for f in fs:
         f.factor_dev(dval.data_ptr())
-        f.wait()
-    total = torch.stack(bufs).sum(dim=0)
-    for xb in bufs:
-        xb.copy_(total)
-    torch.cuda.synchronize()
+    nx = drive_exchanges(fs, bufs)
     for f in fs:
-        f.continue_after_exchange()
         f.wait()
+    if top == "replicated":
+        assert nx == 1
+    else:
+        kinds = fs[0].program("exchanges")[:, 0].tolist()
+        assert kinds[0] == 1 and kinds[-1] == 3 and kinds.count(2) == nx - 2 >= 1, kinds
+        towner = fs[0].partition("top_bcol_owner")
+        assert set(towner[towner >= 0].tolist()) == set(range(world))   # every rank owns part of the top tree
     o, rc = oracle_factor(fs[0], val, variant=variant, nthreads=8)
     assert rc == 0
     ref = o.arena()
@@ -422,16 +432,18 @@ def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None):
         f.close()
 
 
-def test_partitioned_not_posdef_is_reported_on_every_rank():
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
+def test_partitioned_not_posdef_is_reported_on_every_rank(top):
     """A non-positive pivot inside ONE rank's subtree: the indicator travels with the
-    exchange buffer, so every rank-engine reports SPLLT_ERROR_NOT_POSDEF (-20) after the
+    exchange buffer (replicated top tree: with the extend-add; distributed: in an exchange of
+    its own at the end), so every rank-engine reports SPLLT_ERROR_NOT_POSDEF (-20) after the
     top tree instead of factorizing a garbage top tree and returning success."""
     torch = _torch()
     A = matgen.poisson2d(24).tolil()
     world = 2
     fs, bufs = [], []
     for r in range(world):
-        f, val = make_case(A.tocsc(), nb=16, nemin=8, prune=True, ncpu=world)
+        f, val = make_case(A.tocsc(), nb=16, nemin=8, prune=True, ncpu=world, engine_flags=DIST_TOP[top])
         xb = torch.zeros(f.set_partition(r, world), dtype=torch.float64, device="cuda")
         f.set_exchange_buffer(xb.data_ptr())
         fs.append(f)
@@ -447,13 +459,18 @@ def test_partitioned_not_posdef_is_reported_on_every_rank():
     for f in fs:
         f.factor_dev(dval.data_ptr())
         f.wait()          # phase 1 only drains the streams: no error yet
-    total = torch.stack(bufs).sum(dim=0)
-    assert total[-1].item() == 1.0        # exactly one rank raised the indicator
-    for xb in bufs:
-        xb.copy_(total)
-    torch.cuda.synchronize()
+    seen = []
+
+    def indicator(k, kind, src):
+        if kind in (0, 3):     # the exchanges that carry the indicator (last element they cover)
+            e = int(fs[0].program("exchanges")[k][3])
+            seen.append(sum(float(s[e - 1].item()) for s in src))
+    drive_exchanges(fs, bufs, on_exchange=indicator)
+    # replicated: exactly one rank raised the indicator at the exchange point; distributed: the
+    # indicator is exchanged at the very end, by when the broken values have reached the top
+    # tree, where other ranks' pivots may fail as well
+    assert len(seen) == 1 and (seen[0] == 1.0 if top == "replicated" else seen[0] >= 1.0)
     for r, f in enumerate(fs):
-        f.continue_after_exchange()
         with pytest.raises(api.SplltError) as e:
             f.wait()
         assert e.value.flag == -20, r

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, case, ret):
+def _worker(rank, world, port, case, top, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -25,14 +25,16 @@ def _worker(rank, world, port, case, ret):
         from spllt_amd import matgen, multigpu
         A = {"p2d": lambda: matgen.poisson2d(28), "box": lambda: matgen.nd_like((9, 8, 8), 2),
              "p3d": lambda: matgen.poisson3d(9)}[case]()
-        f, val = make_case(A, nb=16, nemin=8, prune=True, ncpu=world, panel_width=16)
+        f, val = make_case(A, nb=16, nemin=8, prune=True, ncpu=world, panel_width=16,
+                           engine_flags={"replicated": 16384, "distributed": 8192}[top])
         xel = f.set_partition(rank, world)
         owner = f.partition("owner")
+        plan = multigpu.exchange_plan(f)
 
-        def exchange(xbuf):
+        def exchange(k, xbuf):
             assert xbuf.size == xel
             t = torch.from_numpy(xbuf.copy())
-            multigpu.reduce_exchange_buffer(t)
+            multigpu.run_exchange(t, plan[k], rank, world)      # the production collective, over gloo
             return t.numpy()
 
         got = emulate_program(f, val, exchange=exchange, partitioned=True)
@@ -52,25 +54,30 @@ def _worker(rank, world, port, case, ret):
         ntop = int((owner < 0).sum())
         L = f.program("launches")
         ret[rank] = (float(err), bool(untouched), nsub, ntop, int((L[:, 0] == 2).sum()),
-                     sorted(set(owner.tolist())))
+                     sorted(set(owner.tolist())), [p[0] for p in plan])
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
 @pytest.mark.parametrize("case,world", [("p2d", 2), ("box", 2), ("p3d", 3)])
-def test_partitioned_program_over_gloo(case, world):
+def test_partitioned_program_over_gloo(case, world, top):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000) + world
+    port = 29500 + (os.getpid() % 2000) + world + (10 if top == "distributed" else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case, top, ret), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
-        err, untouched, nsub, ntop, nx, owners = ret[rank]
+        err, untouched, nsub, ntop, nx, owners, kinds = ret[rank]
         assert err < 1e-13, (rank, err)
         assert untouched            # other ranks' subtrees are never written here
         assert nsub >= world and ntop >= 1
-        assert nx == 1              # exactly one exchange point
+        if top == "replicated":
+            assert nx == 1 and kinds == [0]          # exactly one exchange point: the all-reduce
+        else:
+            # reduce-scatter to the owners, a broadcast per finished block-column step, the indicator
+            assert nx == len(kinds) >= 3 and kinds[0] == 1 and kinds[-1] == 3 and set(kinds[1:-1]) == {2}
         assert set(owners) == set(range(world)) | {-1}
 
 
@@ -103,7 +110,7 @@ def test_owner_assignment_is_balanced_and_covers_subtrees():
         assert (owner == -1).sum() < 0.25 * nn
 
 
-def _gpu_worker(rank, world, port, ret, stream_ordered=False):
+def _gpu_worker(rank, world, port, ret, stream_ordered=False, dist_top=False):
     """one process per rank, every rank on device 0, reduction over gloo: the production
     DistributedFactorization (factor with the exchange on the engine's stream, then the
     three-phase solve) end to end"""
@@ -123,7 +130,8 @@ def _gpu_worker(rank, world, port, ret, stream_ordered=False):
         from spllt_amd import api, matgen, multigpu
         A = matgen.nd_like((11, 10, 9), 2)
         n, ptr, row, val = api.csc_lower_1based(A)
-        df = multigpu.DistributedFactorization(n, ptr, row, 48, rank, world, nemin=16)
+        df = multigpu.DistributedFactorization(n, ptr, row, 48, rank, world, nemin=16, dist_top=dist_top)
+        assert df.dist_top == dist_top and len(df.plan) == (1 if not dist_top else len(df.plan)) >= 1
         dval = torch.tensor(val, device="cuda")
         torch.cuda.synchronize()
         df.factor(dval)
@@ -142,14 +150,19 @@ def _gpu_worker(rank, world, port, ret, stream_ordered=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dist_top", [False, True])
 @pytest.mark.parametrize("stream_ordered", [False, True])
-def test_distributed_factorization_two_processes_one_gpu(stream_ordered):
+def test_distributed_factorization_two_processes_one_gpu(stream_ordered, dist_top):
+    """spllt_amd.multigpu.DistributedFactorization in two processes that share the one GPU, over
+    gloo: top tree replicated (one all-reduce) or distributed (reduce-scatter to the owners, a
+    broadcast per block-column step); the collectives ordered by host syncs or enqueued under
+    the engine's stream (the RCCL code path)."""
     import torch.multiprocessing as mp
     world = 2
-    port = 31500 + (os.getpid() % 2000) + (7 if stream_ordered else 0)
+    port = 31500 + (os.getpid() % 2000) + (7 if stream_ordered else 0) + (14 if dist_top else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_gpu_worker, args=(world, port, ret, stream_ordered), nprocs=world, join=True)
+    mp.spawn(_gpu_worker, args=(world, port, ret, stream_ordered, dist_top), nprocs=world, join=True)
     assert len(ret) == world
     for rank in range(world):
         bwd, err, phases = ret[rank]

@@ -148,6 +148,21 @@ def _access_sets(f):
                 R.append((b, c0, c0 + pn, cs, c0))
                 R.append(("wi", b, c0 // pw))
                 W.append(("ww", b, c0 // pw))      # W part of Winv
+        elif kind == 2:
+            # exchange: the pack reads, the unpack overwrites whole block columns (engine.cpp
+            # pre_exchange / post_exchange)
+            xk, xfirst, xn = (int(v) for v in f.program("exchanges")[first][:3])
+            rank = getattr(f, "rank", 0)
+            for b, root, xo, cnt, xoff_, space in f.program("xitems")[xfirst:xfirst + xn].tolist():
+                if space:      # the block column's dinv slots: the inverses of all its panels
+                    whole = [("wi", b, p) for p in range(-(-int(bw[b]) // pw))]
+                else:
+                    assert cnt == int(bnr[b]) * int(bw[b]) and xoff_ == off[b]
+                    whole = [(b, 0, int(bnr[b]), 0, int(bw[b]))]
+                if xk in (0, 1) or (xk == 2 and root == rank):
+                    R.extend(whole)
+                if xk == 0 or (xk == 1 and root == rank) or (xk == 2 and root != rank):
+                    W.extend(whole)
         elif kind == 7:
             pu = f.program("panels")
             tl = tiles[first:first + count]
