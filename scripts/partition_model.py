@@ -2,13 +2,18 @@
 """What the subtree partition would deliver on w GPUs, measured on ONE device, one rank-engine
 per process (a fresh device heap each time: engines that share a fragmented heap run slower):
 
-    python scripts/partition_model.py <config> <width> <rank>      -> one JSON line
+    python scripts/partition_model.py <config> <width> <rank> [dist]      -> one JSON line
 
-rank r of a width-w partition runs its own-subtree phase alone; rank 0 also runs the
-replicated top-tree phase (on its own, unsummed exchange buffer: the top tree then misses the
-other ranks' Schur complements, which changes the values but neither the structure nor the
-positive definiteness, so the time is the same).  t(w) ~ max_r t_sub(r) + t_allreduce(volume)
-+ t_top.  scripts/partition_model.sh loops over the ranks and prints the summary."""
+rank r of a width-w partition runs its program alone: the own-subtree phase, then the top-tree
+phase with the collectives left out (the exchange buffer then holds only this rank's own data:
+the top tree misses the other ranks' contributions, which changes the values but neither the
+structure nor the work, so the time is the same).
+  replicated top tree (default): only rank 0 runs the top phase (every rank would do the same);
+      t(w) ~ max_r t_sub(r) + t_allreduce(volume) + t_top
+  dist: every rank runs its share of the distributed top tree (the panel chains of the block
+      columns it owns and the updates of the destinations it owns);
+      t(w) ~ max_r t_sub(r) + t_reduce_scatter + max(max_r t_top(r), chain of the top tree) + broadcasts
+scripts/partition_model.sh loops over the ranks and prints the summary."""
 import json
 import os
 import sys
@@ -20,28 +25,44 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spllt_amd import api, matgen  # noqa: E402
 
 cfg_name, w, r = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+dist = len(sys.argv) > 4 and sys.argv[4] == "dist"
 A, order, cfg = matgen.build_config(cfg_name, 1.0)
 n, ptr, row, val = api.csc_lower_1based(A)
 dval = torch.tensor(val, device="cuda")
-f = api.Factorization(n, ptr, row, nb=cfg["nb"], nemin=32, prune_tree=w > 1, ncpu=w, order=order)
+f = api.Factorization(n, ptr, row, nb=cfg["nb"], nemin=32, prune_tree=w > 1, ncpu=w, order=order,
+                      engine_flags=(8192 if dist else 16384) if w > 1 else 0)
 xel = 0
 if w > 1:
     xel = f.set_partition(r, w)
     xb = torch.zeros(max(xel, 1), dtype=torch.float64, device="cuda")
     f.set_exchange_buffer(xb.data_ptr())
 tsub = ttop = None
-for rep in range(2):   # second repetition is the measurement (the other ranks stop at the exchange point)
+nx = 0
+for rep in range(2):   # second repetition is the measurement
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     f.factor_dev(dval.data_ptr())
     f.wait()
     tsub = (time.perf_counter() - t0) * 1e3
-    if w > 1 and r == 0:     # only rank 0's buffer holds the top tree's own entries of A
+    if w > 1 and (dist or r == 0):     # replicated: only rank 0's buffer holds the top tree's own entries of A
         t0 = time.perf_counter()
-        f.continue_after_exchange()
-        f.wait()
+        nx = 0
+        while f.pending_exchange() >= 0:
+            f.continue_after_exchange()      # (no collective: see above)
+            nx += 1
+        try:
+            f.wait()
+        except api.SplltError:
+            pass                             # incomplete sums: a pivot may fail, the work is the same
         ttop = (time.perf_counter() - t0) * 1e3
+ex = f.program("exchanges") if w > 1 else []
+vol = {int(k): 0 for k in (0, 1, 2)}
+for kind, first, nit, elems, chunk in (ex.tolist() if w > 1 else []):
+    if kind in vol:
+        vol[kind] += elems
 si = f.sym_info()
-print(json.dumps({"config": cfg_name, "width": w, "rank": r, "subtree_ms": round(tsub, 2),
-                  "top_ms": None if ttop is None else round(ttop, 2), "exchange_MB": round(xel * 8 / 1e6, 1),
+print(json.dumps({"config": cfg_name, "width": w, "rank": r, "top": "distributed" if dist else "replicated",
+                  "subtree_ms": round(tsub, 2), "top_ms": None if ttop is None else round(ttop, 2),
+                  "exchanges": nx, "allreduce_MB": round(vol[0] * 8 / 1e6, 1),
+                  "reduce_scatter_MB": round(vol[1] * 8 / 1e6, 1), "broadcast_MB": round(vol[2] * 8 / 1e6, 1),
                   "flops_sym_G": round(si["flops"] / 1e9, 1)}), flush=True)

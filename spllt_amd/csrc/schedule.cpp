@@ -988,19 +988,34 @@ void assign_top_owners(const Symbolic& S, const std::vector<int>& node_owner, in
 
 bool distribute_top_tree(const Symbolic& S, const std::vector<int>& node_owner, int nranks) {
   if (nranks < 2) return false;
-  // flops of the top tree (the reference's symbolic count per node, spllt_analyse_mod:1007-1023)
+  // Model of the top-tree phase (the same constants as latency_bound): its panel chains are a
+  // dependent sequence either way -- one ~60 us step per 64 columns of the widest node of every
+  // level -- and its flops (the reference's symbolic count, spllt_analyse_mod:1007-1023) are
+  // repeated on every rank when replicated, shared when distributed, which in turn pays a
+  // broadcast (~100 us: pack, launch, hand-over, unpack) per block-column step:
+  //   replicated   max(chain, flops / rate)
+  //   distributed  max(chain + steps * 100 us, flops / (nranks * rate))
+  // A chain-bound top tree (small problems) stays replicated.
+  int maxlevel = -1;
+  for (int s = 0; s < S.nnodes; ++s) maxlevel = std::max(maxlevel, S.level[s]);
+  std::vector<int> widest((size_t)maxlevel + 1, 0), nsteps((size_t)maxlevel + 1, 0);
   double top_flops = 0;
-  int64_t steps = 0;
   for (int s = 0; s < S.nnodes; ++s) {
     if (node_owner[(size_t)s] >= 0) continue;
     const double m = S.nrow(s), n = S.ncol(s);
     for (int j = 1; j <= (int)n; ++j) top_flops += (m - n + j) * (m - n + j);
-    steps += S.node_bcol0[s + 1] - S.node_bcol0[s];
+    widest[(size_t)S.level[s]] = std::max(widest[(size_t)S.level[s]], S.ncol(s));
+    nsteps[(size_t)S.level[s]] = std::max(nsteps[(size_t)S.level[s]], S.node_bcol0[s + 1] - S.node_bcol0[s]);
   }
-  // replicated: every rank spends top_flops / rate; distributed: 1 / nranks of that, plus one
-  // broadcast (launch + hand-over, ~60 us) per block column step
-  const double saved_us = top_flops * (1.0 - 1.0 / nranks) / 45e6;   // 45 TFLOP/s
-  return saved_us > 60.0 * (double)steps;
+  double chain_us = 0, steps = 0;
+  for (int l = 0; l <= maxlevel; ++l) {
+    chain_us += 60.0 * ((widest[(size_t)l] + 63) / 64);
+    steps += nsteps[(size_t)l];
+  }
+  const double flops_us = top_flops / 45e6;   // 45 TFLOP/s
+  const double t_rep = std::max(chain_us, flops_us);
+  const double t_dist = std::max(chain_us + 100.0 * steps, flops_us / nranks);
+  return t_dist < 0.9 * t_rep;
 }
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P) {

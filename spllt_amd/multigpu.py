@@ -1,18 +1,23 @@
-"""Multi-GPU factorization: one process per GPU, subtree partition, one RCCL
-exchange.
+"""Multi-GPU factorization: one process per GPU, subtree partition, RCCL exchanges on the
+engine's stream.
 
 Every rank analyses the same pattern and maps the assembly tree onto the ranks
 proportionally (symbolic.cpp, assign_owners: whole branches per rank, the nodes
-whose subtrees span several ranks form the replicated top tree - the role the
+whose subtrees span several ranks form the top tree - the role the
 pruning layer of spllt_prune_tree, reference src/spllt_analyse_mod.F90:806-987,
 plays for the reference's sequential subtrees), owns the branches assigned to it,
 and accumulates its contributions to the
 top tree in its own (zero-initialised) copy of the top-tree block columns.  The
 extend-add of the reference -- generated element + spllt_scatter_block
 (src/spllt_factorization_mod.F90:39-191, src/spllt_kernels_mod.F90:1122-1160)
--- becomes ONE all-reduce(sum) of that arena slice over xGMI, enqueued on the
-engine's own stream (no host synchronisation between the phases); the top tree is
-then factorized on every rank (v1: replicated; SURVEY 8(e) "top tree v1").
+-- becomes a collective over xGMI, enqueued on the engine's own stream (no host
+synchronisation between the phases):
+  * replicated top tree: ONE all-reduce(sum); the top tree is then factorized on every rank;
+  * distributed top tree (the reference's PaRSEC build distributes blocks 1-D cyclically,
+    src/PaRSEC/spllt_parsec_blk_data.c:33-64): ONE reduce-scatter(sum) to the owners of the
+    top-tree block columns, then one broadcast per finished block-column step; every rank
+    updates only the destination block columns it owns.
+The engine's program lists the exchanges (exchange_plan); run_exchange is the collective of one.
 
 torch is used only for device memory and torch.distributed (plumbing).
 """
