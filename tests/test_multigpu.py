@@ -168,3 +168,44 @@ def test_distributed_factorization_two_processes_one_gpu(stream_ordered, dist_to
         bwd, err, phases = ret[rank]
         assert bwd <= 1e-14 and err <= 1e-9, (rank, bwd, err)
         assert phases == ["exchange", "subtrees", "top"]
+
+
+def _rccl_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from spllt_amd import multigpu
+        st = torch.cuda.Stream()
+        ext = torch.cuda.ExternalStream(st.cuda_stream)      # like the engine's stream in production
+        x = torch.arange(1000, dtype=torch.float64, device="cuda")
+        ref = x.clone()
+        scratch = torch.empty(600, dtype=torch.float64, device="cuda")
+        plan = [(multigpu.X_REDUCE_OWNER, 600, 600, []),          # one rank: its chunk is everything
+                (multigpu.X_BCAST, 900, 0, [(0, 0, 300), (0, 300, 600)]),
+                (multigpu.X_REDUCE_ALL, 1000, 0, []), (multigpu.X_FLAG, 1, 0, [])]
+        with torch.cuda.stream(ext):
+            for step in plan:
+                multigpu.run_exchange(x, step, 0, 1, None, scratch, force=True)
+        st.synchronize()
+        ret[0] = bool(torch.equal(x, ref))      # sums / broadcasts over one rank change nothing
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_run_exchange_calls_on_rccl_single_rank():
+    """The collectives of multigpu.run_exchange (all-reduce, reduce_scatter_tensor into the
+    scratch + copy to the rank's chunk, broadcasts of buffer slices) issued on a real RCCL
+    process group under an ExternalStream, as in production -- with the one rank this box has.
+    Checks the call signatures / views RCCL accepts; the multi-rank semantics are covered over
+    gloo."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, 33500 + (os.getpid() % 2000), ret), nprocs=1, join=True)
+    assert ret.get(0) is True
