@@ -134,10 +134,9 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
-/* edge of the diagonal sub-tiles the single-workgroup panel-chain kernel walks
- * (default 64 = one panel, rounded down to a multiple of the panel width; before the
- * first spllt_factor).  Larger values let one chain kernel also solve and update the rows
- * of its sub-tile (fewer launches, more work on one CU). */
+/* Accepted and ignored.  (It set the edge of diagonal sub-tiles that a single-workgroup chain
+ * kernel walked, several panels per sub-tile; that variant was slower at every setting and has
+ * been removed: the chain block is always one panel.) */
 int spllt_hip_set_chain_block(void *fkeep, int chain_block);
 
 /* ---- multi-GPU: one process per GPU, subtree partition ----------------------

@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     u.src_r0 = N; u.src_c0 = 0; u.M = M; u.N = N; u.k0 = 0; u.klen = -1; u.d_ld = N;
     u.d_row0 = 0; u.d_col0 = 0; u.mode = MODE_DIRECT; u.lower = 0; u.b_bcol0 = -1;
     u.a_off = 0; u.a_w = K;   // block column of segment 0 (carried by the unit)
+    if (getenv("UB_ATOMIC")) u.atomic = 1;   // epilogue: atomic subtract instead of read-modify-write
     UpdUnit* du;
     hipMalloc(&du, sizeof(u));
     hipMemcpy(du, &u, sizeof(u), hipMemcpyHostToDevice);

@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <chrono>
+#include <thread>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,44 @@ int Engine::fail(int code, const char* what, hipError_t e) {
   err_ = std::string(what) + ": " + hipGetErrorString(e);
   std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
   return code;
+}
+
+int Engine::sync_stream(hipStream_t st, const char* what) {
+  static const double limit_s = [] {
+    const char* e = std::getenv("SPLLT_HIP_TIMEOUT_S");
+    return (e && *e) ? std::atof(e) : 180.0;
+  }();
+  if (limit_s <= 0) {
+    hipError_t e = hipStreamSynchronize(st);
+    return e == hipSuccess ? 0 : fail(kErrHip, what, e);
+  }
+  const double t0 = now_ms();
+  for (;;) {
+    hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(kErrHip, what, q);
+    const double dt = now_ms() - t0;
+    if (dt > limit_s * 1e3) break;
+    if (dt > 20.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else std::this_thread::yield();
+  }
+  // the device does not finish: say where the program stands
+  std::string rep = std::string(what) + ": the stream did not drain within " + std::to_string((int)limit_s) + " s;";
+  int shown = 0;
+  for (size_t i = 0; i < prog_.launches.size() && shown < 4; ++i) {
+    const Launch& l = prog_.launches[i];
+    if (l.record < 0 || hipEventQuery(dag_events_[(size_t)l.record]) == hipSuccess) continue;
+    rep += " launch " + std::to_string(i) + " (kind " + std::to_string(l.kind) + ", level " + std::to_string(l.level) +
+           ", count " + std::to_string((long long)l.count) + ", tile " + std::to_string(l.tile) + ", stream " +
+           std::to_string(l.stream) + ") has not finished;";
+    ++shown;
+  }
+  for (int i = 0; i < ST_COUNT; ++i)
+    if (streams_[i]) rep += " stream " + std::to_string(i) + (hipStreamQuery(streams_[i]) == hipSuccess ? " idle;" : " busy;");
+  status_ = kErrHip;
+  err_ = rep;
+  std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
+  return kErrHip;
 }
 
 template <class Tp>
@@ -241,9 +280,7 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
   if (l.count > 0 && l.kind != L_EXCHANGE) {
     if (opt_.poison_lds) launch_poison_lds(st);
     if (l.kind == L_CHAIN) {
-      launch_chain_panel(st, d_chain_ + l.first, l.count, l.tile, d_L_, d_dinv_, d_flag_);
-    } else if (l.kind == L_WINV) {
-      launch_winv(st, d_chain_ + l.first, l.count, d_L_, d_dinv_);
+      launch_chain_panel(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
     } else if (l.kind == L_PANEL) {
       launch_panel(st, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
     } else if (l.kind == L_GATHER) {
@@ -348,7 +385,11 @@ int Engine::post_exchange(const Launch& X) {
 
 int Engine::sync_phase() {
   if (status_) return status_;
-  for (hipStream_t st : streams_) HIPCHK(hipStreamSynchronize(st), "stream sync");
+  for (hipStream_t st : streams_)
+    if (st) {
+      int rc = sync_stream(st, "stream sync");
+      if (rc) return rc;
+    }
   return 0;
 }
 
@@ -401,7 +442,10 @@ int Engine::wait() {
   if (status_) return status_;
   if (!pending_) return 0;
   if (awaiting_exchange_) return sync_phase();  // not finished: only drain phase 1
-  HIPCHK(hipStreamSynchronize(stream_), "stream sync");
+  {
+    int rc = sync_stream(stream_, "stream sync");
+    if (rc) return rc;
+  }
   pending_ = false;
   float ms = 0;
   if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) stats_.device_ms = ms;
@@ -462,8 +506,7 @@ int Engine::solve_dev(double* y_dev, int nrhs, int job, int phase) {
     done += cur;
   }
   HIPCHK(hipGetLastError(), "solve launch");
-  HIPCHK(hipStreamSynchronize(stream_), "solve sync");
-  return 0;
+  return sync_stream(stream_, "solve sync");
 }
 
 int Engine::solve(double* x_host, int nrhs, int job) {

@@ -18,7 +18,7 @@ namespace spx {
 struct EngineOptions {
   int pw = 64;
   int tile = 128;
-  int cb = 64;             // chain block (edge of the diagonal sub-tiles of the panel chain)
+  int cb = 64;             // ignored (see ScheduleOptions)
   bool lookahead = true;   // multi-stream program (panel chain overlaps trailing updates)
   bool slice_between = true;  // inter-node updates in K slices beside the panel chains
   bool deterministic = false;  // see ScheduleOptions
@@ -103,6 +103,10 @@ class Engine {
   int finish_enqueue();
   int enqueue_launch(const Launch& l, bool serial);
   int fail(int code, const char* what, hipError_t e);
+  // hipStreamSynchronize with a deadline (SPLLT_HIP_TIMEOUT_S, default 180 s; 0 = wait forever):
+  // a stream that does not drain makes the call FAIL with a report of the first launch of the
+  // program whose event has not fired, instead of blocking the caller forever
+  int sync_stream(hipStream_t st, const char* what);
 
   std::shared_ptr<const Symbolic> S_;
   EngineOptions opt_;

@@ -4,12 +4,9 @@
 //   k_chain_potrf   a11 spllt_factor_diag_block (:1168-1189) on one <=64-wide panel per
 //                   workgroup, also emits the inverse of the factored panel (the default
 //                   chain step); k_potrf_panel: the same body for the operator twins
-//   k_chain_panel   the chain step when the chain block is wider than a panel: POTRF of the
-//                   panel, the rows of its diagonal sub-tile below it and their update of
-//                   the rest of the sub-tile in ONE workgroup
-//   k_winv          W part of Winv = [ -inv(L_pp) L[p, cs:c0] | inv(L_pp) ], which turns the
-//                   left-looking update + TRSM of a row block into one k_update product
-//   k_update<T>     a12 spllt_solve_block (:1217) as X = [X_left | A] * Winv^T,
+//   k_panel         a whole panel step of a block column with few rows in one launch: POTRF,
+//                   the rows below (a12) and the left-looking update of the next panel (a13)
+//   k_update<T>     a12 spllt_solve_block (:1217) as X = A * inv(L_pp)^T,
 //                   a13 spllt_update_block (:1261-1292),
 //                   a16+a18 spllt_update_between + spllt_expand_buffer
 //                   (:2108-2237, :2010-2053) with the scatter fused into the GEMM
@@ -132,7 +129,7 @@ struct PotrfShared {
   double X[64 * TLD];
   double DI[4][16 * DLD];
   double RI[64];  // reciprocals of the diagonal of L
-  double T[64 * TLD];  // last: k_chain_panel reuses it (and the dynamic LDS behind it) as its U buffer
+  double T[64 * TLD];  // last: k_panel reuses it (and the dynamic LDS behind it) for its row blocks
 };
 
 // Factor (and invert) one <=64 x <=64 block held at A (row stride ld); the whole
@@ -348,27 +345,18 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// One step of the panel chain (ChainUnit), ONE workgroup per block column: panel
-// [c0, c0+pn) of the diagonal sub-tile [cs, ce) x [cs, ce) of a block column
-// (a11 spllt_factor_diag_block restricted to the sub-tile, right-looking):
-//   1. L_pp = chol(A_pp), inv(L_pp) -> last pn columns of Winv           (potrf64_body)
-//   2. X = A[c0+pn:ce, c0:c0+pn] inv(L_pp)^T                          (rows of the sub-tile)
-//   3. A[c0+pn:ce, c0+pn:ce] -= X X^T  (lower part)
-// k_winv (side stream, off the chain) completes
-//      Winv = [ -inv(L_pp) A[c0:c0+pn, cs:c0] | inv(L_pp) ]           in the dinv scratch,
-// which turns the left-looking update AND the triangular solve of every row below
-// the sub-tile into ONE product with K = c0+pn-cs (k_update, TRSM mode):
-//   X_r = [X_r,cs:c0 | A_r,c0:c0+pn] Winv^T
-// so the rows below never enter the chain: per panel the critical path is this one
-// kernel instead of a POTRF, a TRSM and an update launch.
-// LDS: PotrfShared, whose T (dead after step 1) and the dynamic LDS behind it hold
-// U = X (up to ce-c0-pn rows, zero padded to a multiple of 16).
+// One step of the panel chain (ChainUnit), one workgroup per block column: panel [c0, c0+pn)
+// of a block column (a11 spllt_factor_diag_block): L_pp = chol(A_pp) and inv(L_pp) into the
+// dinv scratch, which turns the triangular solve of the rows below into a product
+// (k_update, TRSM mode) and is what the solve phase applies.  256 threads and static LDS: two
+// workgroups per CU -- the leaf levels of a large problem are thousands of such panels and run
+// at the rate the chip retires these workgroups.
+// (Round 2 also had a 768-thread k_chain_panel that walked diagonal sub-tiles wider than a
+// panel -- solve and update of the sub-tile's rows inside the chain kernel, a k_winv kernel
+// for the left part of the rows below -- selected by a "chain block" knob.  It was slower at
+// every setting and every one of the three hangs this repository has
+// seen on the GPU box happened in a case that used it; it has been removed.)
 // ---------------------------------------------------------------------------
-// The chain step of a panel that is its whole sub-tile (chain block = panel width, the default):
-// nothing but the POTRF and its inverse.  256 threads and static LDS: two workgroups per CU
-// instead of the one that the 768-thread kernel below gets -- the leaf levels of a large
-// problem are thousands of such panels and run at the rate the chip retires these workgroups
-// (k_chain_panel there: 171 of 278 ms of kernel time on Poisson3D 128^3).
 __global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict__ units,
                                                      double* __restrict__ L,
                                                      double* __restrict__ dinv,
@@ -379,109 +367,6 @@ __global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict
   const int cq = u.c0 - u.cs;
   potrf64_body(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, cq + u.pn,
                u.gcol, 0, flag);
-}
-
-constexpr int kChainThreads = 768;    // 12 waves: a single wave issues an fp64 MFMA only every
-                                      // ~150 cycles; three per SIMD fit the register budget of the POTRF part (158 VGPRs)
-
-__global__ __launch_bounds__(kChainThreads) void k_chain_panel(const ChainUnit* __restrict__ units,
-                                                               double* __restrict__ L,
-                                                               double* __restrict__ dinv,
-                                                               int* __restrict__ flag) {
-  extern __shared__ __attribute__((aligned(16))) double chain_smem[];
-  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(chain_smem);
-  double* U = sh.T;
-  __builtin_amdgcn_s_setprio(3);
-  const ChainUnit u = units[blockIdx.x];
-  constexpr int NW = kChainThreads / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int ld = u.ld, c0 = u.c0, pn = u.pn, cq = u.c0 - u.cs;
-  const int ldw = cq + pn;
-  double* A = L + u.off;
-  double* W = dinv + u.winv_off;
-  potrf64_body(sh, A + (int64_t)c0 * ld + c0, ld, pn, W + cq, ldw, u.gcol, 0, flag);
-  __syncthreads();   // T has been read back: it may be overwritten now
-  STAMP(17);
-  // From here on every inner loop runs its full 16 k-steps / 4 column blocks without
-  // branches and loads at clamped addresses without conditions (a load under a condition
-  // is compiled into a branch with its own wait; unconditional ones are requested
-  // together): X is zero outside [0, pn) x [0, pn) except for the identity padding of its
-  // diagonal, which only ever meets zeroed or discarded operands.
-  // ---- 2. rows of the sub-tile below the panel: X = A inv(L_pp)^T ----------------
-  // one (16-row strip, 16-column block) pair per wave and turn
-  const int r1 = c0 + pn;
-  const int nrem = u.ce - r1;
-  const int ns = (nrem + 15) >> 4;
-  for (int t = wave; t < ns * 4; t += NW) {
-    const int s = t >> 2, jb = t & 3;
-    // operands at clamped addresses, no selection: rows beyond the sub-tile duplicate its
-    // last row (their results are never used), columns k >= pn meet the zeros of X, and the
-    // padding columns of the result are cleared at the store
-    const int row = r1 + s * 16 + lr;
-    const double* ap = A + (int64_t)(row < u.ce ? row : u.ce - 1) * ld + c0;
-    double av[16], xv[16];
-#pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
-      const int k = 4 * kt + lq;
-      av[kt] = ap[k < pn ? k : pn - 1];
-      xv[kt] = sh.X[(jb * 16 + lr) * TLD + k];
-    }
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kt = 0; kt < 16; kt += 2) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], xv[kt], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], xv[kt + 1], acc1, 0, 0, 0);
-    }
-    // the four waves of a strip read the same rows of A before any of them stores:
-    // each stores only its own 16 columns, and those are read by ... every wave of
-    // the strip.  So the stores wait for the strip's loads: barrier below.
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      U[(s * 16 + lq + 4 * r) * TLD + jb * 16 + lr] = (jb * 16 + lr < pn) ? acc0[r] + acc1[r] : 0.0;
-  }
-  __syncthreads();
-  // X back to the arena (the in-place overwrite is safe now: every load of step 3 is done)
-  for (int e = tid; e < nrem * 64; e += kChainThreads) {
-    const int rr = e >> 6, col = e & 63;
-    if (col < pn) A[(int64_t)(r1 + rr) * ld + c0 + col] = U[rr * TLD + col];
-  }
-  STAMP(19);
-  // ---- 3. A[r1:ce, r1:ce] -= X X^T (lower), 16x16 tiles dealt to the waves ---------
-  {
-    const int npairs = ns * (ns + 1) / 2;
-    int ib = 0, base = 0;   // pairs of row strip ib occupy [base, base + ib]
-    for (int p = wave; p < npairs; p += NW) {
-      while (p > base + ib) { base += ib + 1; ++ib; }
-      const int jb = p - base;
-      d4 acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
-      bool ok[4];
-      const int col = r1 + jb * 16 + lr;
-      const int colc = col < u.ce ? col : u.ce - 1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r1 + ib * 16 + lq + 4 * r;
-        ok[r] = row < u.ce && col < u.ce && row >= col;
-        acc0[r] = A[(int64_t)(row < u.ce ? row : u.ce - 1) * ld + colc];   // unconditional, clamped
-      }
-      double av[16], bv[16];
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt) {
-        av[kt] = -U[(ib * 16 + lr) * TLD + 4 * kt + lq];
-        bv[kt] = U[(jb * 16 + lr) * TLD + 4 * kt + lq];
-      }
-#pragma unroll
-      for (int kt = 0; kt < 16; kt += 2) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], bv[kt], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], bv[kt + 1], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r1 + ib * 16 + lq + 4 * r;
-        if (ok[r]) A[(int64_t)row * ld + col] = acc0[r] + acc1[r];
-      }
-    }
-  }
-  STAMP(20);
 }
 
 // ---------------------------------------------------------------------------
@@ -674,53 +559,6 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
   }
 }
 
-// W part of Winv for the panels of a launch of k_chain_panel (same ChainUnit): one workgroup
-// per unit, 16 x 16 tiles dealt to its waves.  Side stream: only the rows below the sub-tile
-// wait for it.
-__global__ __launch_bounds__(kChainThreads) void k_winv(const ChainUnit* __restrict__ units,
-                                                        const double* __restrict__ L,
-                                                        double* __restrict__ dinv) {
-  __shared__ double X[64 * TLD];
-  const ChainUnit u = units[blockIdx.x];
-  constexpr int NW = kChainThreads / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int ld = u.ld, c0 = u.c0, pn = u.pn, cq = u.c0 - u.cs;
-  const int ldw = cq + pn;
-  const double* A = L + u.off;
-  double* W = dinv + u.winv_off;
-  // inv(L_pp), zero padded to 64 x 64
-  for (int e = tid; e < 64 * 64; e += kChainThreads) {
-    const int i = e >> 6, k = e & 63;
-    const double v = W[(int64_t)(i < pn ? i : pn - 1) * ldw + cq + (k < pn ? k : pn - 1)];
-    X[i * TLD + k] = (i < pn && k < pn) ? v : 0.0;
-  }
-  __syncthreads();
-  const int nib = (pn + 15) >> 4, njb = (cq + 15) >> 4;
-  for (int t = wave; t < nib * njb; t += NW) {
-    const int ib = t % nib, jb = t / nib;
-    const bool jok = jb * 16 + lr < cq;
-    const double* bp = A + u.cs + (jok ? jb * 16 + lr : cq - 1);
-    double bv[16], av[16];
-#pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
-      const int k = 4 * kt + lq;
-      bv[kt] = bp[(int64_t)(c0 + (k < pn ? k : pn - 1)) * ld];
-      av[kt] = X[(ib * 16 + lr) * TLD + k];
-    }
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kt = 0; kt < 16; kt += 2) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], bv[kt], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt + 1], bv[kt + 1], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ib * 16 + lq + 4 * r, j = jb * 16 + lr;
-      if (i < pn && j < cq) W[(int64_t)i * ldw + j] = -(acc0[r] + acc1[r]);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // The update kernel.  One workgroup (WM x WN waves) owns one T x T tile of one
 // unit; each wave owns a (T/WM)x(T/WN) block = FMM x FMN MFMA fragments.  K is streamed in steps of 16 through LDS ([row][k], row stride 18
@@ -753,8 +591,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   constexpr int FMN = T / WN / 16;    // MFMA fragments per wave, columns
   constexpr int PER = T * BK / NT;    // doubles staged per thread per operand per step
   constexpr int TPR = BK / PER;       // threads per tile row
-  __shared__ double As[T * LDK];
-  __shared__ double Bs[T * LDK];
+#ifndef UPD_STAGES
+#define UPD_STAGES 1
+#endif
+  // UPD_STAGES LDS stages of both operand tiles (dynamic LDS).  Two stages (step k+1 written into
+  // the other stage after the MFMAs of step k: one barrier per step) were measured SLOWER: the
+  // 64-tile loses a workgroup per CU to the LDS (58.1 vs 61.3 TFLOP/s at K = 1024, 48.0 vs 51.6
+  // at K = 256, scripts/update_bench.hip -DUPD_STAGES=2)
+  extern __shared__ __attribute__((aligned(16))) double upd_smem[];
+  double* const As = upd_smem;
+  double* const Bs = upd_smem + UPD_STAGES * T * LDK;
 
   const UpdTile tl = tiles[blockIdx.x];
   const UpdUnit u = units[tl.unit];
@@ -847,41 +693,88 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   bool more = klen > 0;
   if (more) load_regs();
 
-  while (more) {
-    __syncthreads();
+  // advance to the next K step (possibly the next K segment); false: none left
+  auto advance = [&]() {
+    kk += BK;
+    if (kk < klen) return true;
+    while (seg + 1 < u.nseg) {
+      seg_setup(++seg);
+      kk = 0;
+      if (klen > 0) return true;
+    }
+    return false;
+  };
+  auto stage = [&](int st) {
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-      As[srow * LDK + skof + e] = ra[e];
-      Bs[srow * LDK + skof + e] = rb[e];
+      As[st * (T * LDK) + srow * LDK + skof + e] = ra[e];
+      Bs[st * (T * LDK) + srow * LDK + skof + e] = rb[e];
     }
-    __syncthreads();
-    // advance to the next K step and start its global loads
-    kk += BK;
-    if (kk >= klen) {
-      more = false;
-      while (seg + 1 < u.nseg) {
-        seg_setup(++seg);
-        kk = 0;
-        if (klen > 0) { more = true; break; }
-      }
+  };
+  // MFMAs of the step in stage st; the operand fragments of sub-step ks+1 are read from LDS
+  // before the MFMAs of sub-step ks are issued
+  auto mfma_step = [&](int st) {
+    const double* Ap = As + st * (T * LDK) + (wm * (T / WM) + (lane & 15)) * LDK + (lane >> 4);
+    const double* Bp = Bs + st * (T * LDK) + (wn * (T / WN) + (lane & 15)) * LDK + (lane >> 4);
+    // (second fragment set only where it is free: the 128-tile would drop from 4 to 3 waves per
+    // SIMD for the 12 extra registers and lose 10 %)
+#ifdef UPD_PIPE_ALL
+    constexpr bool PIPE = true;
+#else
+    constexpr bool PIPE = FMM * FMN <= 4;
+#endif
+    double af[PIPE ? 2 : 1][FMM], bf[PIPE ? 2 : 1][FMN];
+    if (PIPE) {
+#pragma unroll
+      for (int a = 0; a < FMM; ++a) af[0][a] = Ap[a * 16 * LDK];
+#pragma unroll
+      for (int b = 0; b < FMN; ++b) bf[0][b] = Bp[b * 16 * LDK];
     }
-    if (more) load_regs();
-    // MFMAs of the staged step
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      double af[FMM], bf[FMN];
-      const int kq = ks * 4 + (lane >> 4);
+      const int cur = PIPE ? (ks & 1) : 0, nx = PIPE ? ((ks + 1) & 1) : 0;
+      if (!PIPE || ks + 1 < BK / 4) {
+        const int kr = PIPE ? ks + 1 : ks;
 #pragma unroll
-      for (int a = 0; a < FMM; ++a) af[a] = As[(wm * (T / WM) + a * 16 + (lane & 15)) * LDK + kq];
+        for (int a = 0; a < FMM; ++a) af[nx][a] = Ap[a * 16 * LDK + kr * 4];
 #pragma unroll
-      for (int b = 0; b < FMN; ++b) bf[b] = Bs[(wn * (T / WN) + b * 16 + (lane & 15)) * LDK + kq];
+        for (int b = 0; b < FMN; ++b) bf[nx][b] = Bp[b * 16 * LDK + kr * 4];
+      }
 #pragma unroll
       for (int a = 0; a < FMM; ++a)
 #pragma unroll
         for (int b = 0; b < FMN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+    }
+  };
+#if UPD_STAGES == 2
+  if (more) {
+    stage(0);
+    more = advance();
+    __syncthreads();
+    int st = 0;
+    while (true) {
+      // stage st holds step k; the loads of step k+1 fly during its MFMAs
+      const bool nxt = more;
+      if (nxt) load_regs();
+      mfma_step(st);
+      if (!nxt) break;
+      stage(st ^ 1);        // (everybody left this stage before the last barrier)
+      more = advance();
+      __syncthreads();
+      st ^= 1;
     }
   }
+#else
+  while (more) {
+    __syncthreads();
+    stage(0);
+    __syncthreads();
+    more = advance();       // the next K step: its global loads fly during the MFMAs
+    if (more) load_regs();
+    mfma_step(0);
+  }
+#endif
 
   // ---- epilogue --------------------------------------------------------------
   const int lr = lane >> 4, lc = lane & 15;
@@ -1074,7 +967,7 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
   for (int pp = 0; pp < np; ++pp) {
     const int p = BWD ? np - 1 - pp : pp;
     const int c0 = p * pw, pn = min(pw, w - c0);
-    // Winv of panel p (k_chain_panel): pn x (cq + pn), inv(L_pp) = its last pn columns
+    // dinv slot of panel p: pn x (cq + pn) with cq = 0 (chain block = panel), inv(L_pp) = its last pn columns
     int64_t slot = u.dinv_off;
     for (int t = 0; t < p; ++t) {
       const int ct = t * pw, pt = min(pw, w - ct);
@@ -1333,30 +1226,10 @@ void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double*
   hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
 }
 
-// dynamic LDS of k_chain_panel for sub-tiles with up to `max_rows_below` rows below a panel
-static unsigned chain_lds_bytes(int max_rows_below) {
-  const int urows = ((max_rows_below + 15) / 16) * 16;
-  const int extra = urows > 64 ? urows - 64 : 0;
-  return (unsigned)(sizeof(PotrfShared) + sizeof(double) * (size_t)extra * TLD);
-}
-
-void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, int max_rows_below,
-                        double* L, double* dinv, int* flag) {
+void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+                        int* flag) {
   if (count <= 0) return;
-  if (max_rows_below <= 0) {   // every panel of the launch is its whole sub-tile
-    hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
-    return;
-  }
-  thread_local int attr_dev = -1;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev != attr_dev) {
-    (void)hipFuncSetAttribute((const void*)k_chain_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_dev = dev;
-  }
-  hipLaunchKernelGGL(k_chain_panel, dim3((unsigned)count), dim3(kChainThreads), chain_lds_bytes(max_rows_below),
-                     st, units, L, dinv, flag);
+  hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
 }
 
 void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
@@ -1372,11 +1245,6 @@ void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const Pan
   }
   hipLaunchKernelGGL(k_panel, dim3((unsigned)count), dim3(kPanelThreads), lds, st, tiles, units, L, dinv, counters,
                      flag);
-}
-
-void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv) {
-  if (count <= 0) return;
-  hipLaunchKernelGGL(k_winv, dim3((unsigned)count), dim3(kChainThreads), 0, st, units, L, dinv);
 }
 
 // ---------------------------------------------------------------------------
@@ -1471,8 +1339,12 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
   if (count <= 0) return;
   // lds_pad: extra (unused) dynamic LDS that caps the workgroups per CU of a
   // trailing-update launch so that panel-chain kernels find room beside it
-  const unsigned pad = lds_pad > 0 ? (unsigned)lds_pad : 0u;
-  if (pad > 0) {
+  // dynamic LDS: the operand stages of the tile (+ the optional pad)
+  auto lds_of = [&](int T, int BK) {
+    return (unsigned)(sizeof(double) * 2 * UPD_STAGES * T * (BK + UPD_LDK_PAD)) + (lds_pad > 0 ? (unsigned)lds_pad : 0u);
+  };
+  const unsigned pad = tile == 128 ? lds_of(128, UPD128_BK) : tile == 64 ? lds_of(64, 16) : lds_of(32, 32);
+  {
     // the padded launches exceed the default 64 KB of LDS per workgroup; the
     // attribute is per device, so it is (re)applied for the current one
     thread_local int attr_dev = -1;
@@ -1480,9 +1352,11 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
     (void)hipGetDevice(&dev);
     if (dev != attr_dev) {
       (void)hipFuncSetAttribute((const void*)k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       (void)hipFuncSetAttribute((const void*)k_update<64, 16, 2, 2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_update<32, 32, 2, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_dev = dev;
     }
   }

@@ -13,16 +13,13 @@ void launch_scatter_val(hipStream_t st, double* L, const double* val, const int6
                         const int64_t* src, int64_t n);
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag);
-// one step of the panel chain per workgroup (ChainUnit); max_rows_below = most rows of a
-// sub-tile below a panel over the units of the launch (sizes the dynamic LDS)
-void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, int max_rows_below,
-                        double* L, double* dinv, int* flag);
+// one step of the panel chain per workgroup (ChainUnit): POTRF of the panel + its inverse
+void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+                        int* flag);
 // one whole panel step per launch (PanelUnit; tiles: unit, ti = 64-row block below the panel)
 // counters: two zero-initialised ints per panel unit (left zero again by the launch)
 void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
                   double* dinv, int* counters, int* flag);
-// W part of Winv of the same units
-void launch_winv(hipStream_t st, const ChainUnit* units, int64_t count, const double* L, double* dinv);
 // deterministic assembly of buffered inter-node update blocks (GatherTile / GatherItem)
 void launch_gather(hipStream_t st, const GatherTile* tiles, int64_t count, const GatherItem* items,
                    double* L, const double* scratch, const int* relpos, const int* rlist);

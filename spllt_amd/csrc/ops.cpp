@@ -81,9 +81,7 @@ struct OpsBatch {
         if (l.kind == L_POTRF)
           launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag);
         else if (l.kind == L_CHAIN)
-          launch_chain_panel(st, d_chain + l.first, l.count, l.tile, base, d_dinv, d_flag);
-        else if (l.kind == L_WINV)
-          launch_winv(st, d_chain + l.first, l.count, base, d_dinv);
+          launch_chain_panel(st, d_chain + l.first, l.count, base, d_dinv, d_flag);
         else if (l.kind == L_PANEL)
           launch_panel(st, d_tiles + l.first, l.count, d_panel, base, d_dinv, d_pcnt, d_flag);
         else

@@ -382,7 +382,9 @@ struct Builder {
 
   void run() {
     P.pw = pw;
-    const int cb = std::max(pw, (std::max(opt.cb, pw) / pw) * pw);   // multiple of the panel width
+    // chain block = one panel.  (ScheduleOptions::cb once selected wider diagonal sub-tiles walked
+    // by a single-workgroup chain kernel; slower at every setting and removed, see kernels.hip.)
+    const int cb = pw;
     P.cb = cb;
     const int nn = S.nnodes;
     int maxlevel = -1;
@@ -404,6 +406,7 @@ struct Builder {
 
     const bool la = opt.lookahead;
     const bool det = opt.deterministic;
+    const bool pair_sources = env_int("SPLLT_PAIR_TRAILING", opt.pair_sources ? 1 : 0) != 0;
     auto edge = [&](int stream) {
       Edge e;
       e.stream = la ? stream : ST_CHAIN;
@@ -639,41 +642,8 @@ struct Builder {
               }
               if (L.count > 0) P.launches.push_back(L);
             }
-            // (2) rows below the sub-tile: X = [X(:, cs:c0) | A(:, c0:c0+pn)] Winv^T, after the
-            // W part of Winv (k_winv, side stream) for the units that have such rows
+            // (2) rows below the panel: X = A(:, c0:c0+pn) inv(L_pp)^T
             double fl = 0;
-            if (q > 0) {
-              Launch L;
-              L.kind = L_WINV;
-              L.level = lev;
-              L.first = (int64_t)P.chain_units.size();
-              L.tile = 0;
-              for (int s : nodes) {
-                const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-                if (c >= nc) continue;
-                const int b = S.node_bcol0[s] + c;
-                if (!mine(b)) continue;
-                const BlockCol& B = S.bcols[b];
-                const int c0 = cs + q * pw;
-                if (c0 >= std::min(B.width, cs + cb)) continue;
-                const int ce = std::min(B.width, cs + cb);
-                if (B.nrow - ce <= 0) continue;
-                ChainUnit u{};
-                u.off = B.off;
-                u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
-                u.ld = B.width;
-                u.c0 = c0;
-                u.pn = std::min(pw, ce - c0);
-                u.cs = cs;
-                u.ce = ce;
-                u.gcol = S.sptr[s] + B.r0 + c0;
-                P.chain_units.push_back(u);
-              }
-              L.count = (int64_t)P.chain_units.size() - L.first;
-              L.flops = 0;
-              L.stream = ST_CHAIN;
-              if (L.count > 0) P.launches.push_back(L);
-            }
             for (int s : nodes) {
               const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
               if (c >= nc) continue;
@@ -803,11 +773,30 @@ struct Builder {
                   us_n1.push_back(n1);
                   fl_n1 += direct_flops(n1);
                 } else {
+                  // Trailing updates two source block columns at a time (K = 2 nb: the destination
+                  // is read and written once for both, and the update kernel runs 10-15 % faster
+                  // at twice the K): an odd block column c goes together with c-1 into every
+                  // destination from c+2 on; an even one only updates c+2 alone (which cannot
+                  // wait for c+1), the rest follows with its partner.
                   UpdUnit u = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
+                  double fu = direct_flops(u);
+                  if (pair_sources) {
+                    if ((c & 1) == 0) {
+                      if (jj != c + 2) continue;
+                    } else {
+                      u.src_bcol0 = b - 1;
+                      u.nseg = 2;
+                      u.seg_r0 = S.bcols[b - 1].r0;
+                      u.k0 = 0;
+                      u.klen = -1;
+                      u.a_off = 0;
+                      fu *= (double)(S.bcols[b - 1].width + B.width) / B.width;
+                    }
+                  }
                   // zones of the level below may still be adding into this block column
                   if (pipelined) u.atomic = 1;
                   (la ? us_bulk : us_n2).push_back(u);
-                  (la ? fl_bulk : fl_n2) += direct_flops(u);
+                  (la ? fl_bulk : fl_n2) += fu;
                 }
               }
             }

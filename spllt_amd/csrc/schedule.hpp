@@ -4,12 +4,13 @@
 // tile kernel, the elimination tree is cut into levels and every level is a
 // short sequence of *batched* launches whose work lists live in device memory:
 //
-//   per level, per block-column step c, per diagonal sub-tile (cb x cb), per panel p (<= PW):
-//       CHAIN  : k_chain_panel, one workgroup per node: POTRF of the panel's diagonal block
-//                (factorize_block, kernels_mod:1168), solve + update inside the sub-tile
-//       SIDE   : rows below the sub-tile, left-looking update and solve in one product
-//                (solve_block + update_block, kernels_mod:1217, :1261)
-//     UPDATE   : rest of the block column / trailing block columns of the same node
+//   per level, per block-column step c, per panel p (<= PW columns):
+//       CHAIN  : k_chain_potrf, one workgroup per node: POTRF of the panel's diagonal block
+//                (factorize_block, kernels_mod:1168) + its inverse
+//       TRSM   : rows below the panel (solve_block, kernels_mod:1217) as a product with the inverse
+//       UPDATE : left-looking update of the next panel's columns (update_block, :1261)
+//       (or PANEL: all three in one k_panel launch, when the step has few row blocks)
+//     UPDATE   : trailing block columns of the same node
 //   UPDATE/scatter: every (node, ancestor block column) pair of the level
 //                (update_between + expand_buffer, kernels_mod:2108, :2010)
 //
@@ -77,9 +78,9 @@ struct PotrfUnit {
   int flags;         // bit 0: block is already a Cholesky factor, only invert it
 };
 
-// One step of the panel chain (k_chain_panel), one workgroup: panel [c0, c0+pn) of the
-// diagonal sub-tile [cs, ce) of a block column.  winv_off: where Winv goes in the dinv
-// scratch, a pn x (c0-cs+pn) row-major matrix [ -inv(L_pp) L[c0:c0+pn, cs:c0] | inv(L_pp) ].
+// One step of the panel chain (k_chain_potrf), one workgroup: panel [c0, c0+pn) of a block
+// column.  winv_off: where inv(L_pp) goes in the dinv scratch (pn x pn; cs = c0, ce = c0 + pn:
+// the fields of the removed wider "chain block" sub-tiles).
 struct ChainUnit {
   int64_t off;       // arena offset of the block column
   int64_t winv_off;
@@ -131,7 +132,7 @@ struct GatherTile {
 };
 static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
 
-enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, L_WINV = 5, L_GATHER = 6,
+enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, /* 5: removed */ L_GATHER = 6,
                         L_PANEL = 7 };
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
@@ -193,9 +194,9 @@ struct Exchange {
 
 struct Program {
   int pw = 64;  // inner panel width
-  int cb = 64;  // chain block: edge of the diagonal sub-tiles the chain kernels walk
+  int cb = 64;  // = pw (the chain block of the removed sub-tile chain kernels; layout parameter of the dinv slots)
   std::vector<PotrfUnit> potrf_units;  // L_POTRF (operator twins only: inverse of given factors)
-  std::vector<ChainUnit> chain_units;  // L_CHAIN, L_WINV
+  std::vector<ChainUnit> chain_units;  // L_CHAIN
   std::vector<PanelUnit> panel_units;  // L_PANEL (tiles: unit, ti)
   std::vector<GatherItem> gather_items;
   std::vector<GatherTile> gather_tiles;  // L_GATHER
@@ -217,7 +218,7 @@ struct Program {
 struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
-  int cb = 64;          // chain block (rounded down to a multiple of pw)
+  int cb = 64;          // ignored (chain block of the removed sub-tile chain kernels)
   // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree
   // node, -1 for the (replicated) top tree.  With nranks > 1 the program is
   // [own subtrees] EXCHANGE [top tree].
@@ -244,6 +245,7 @@ struct ScheduleOptions {
                               // CUs are free, and a launch that needs a second round of them loses
                               // what the two saved kernel boundaries gain: 26.3 ms unfused, 25.9 with
                               // 64, 26.3 with 128, 28.4 with 512 on the nd24k stand-in)
+  bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
 };

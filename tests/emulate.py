@@ -149,16 +149,6 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                        int(t["col0"]) + np.arange(cols)[None, :])
                 arena[idx] -= acc[:rows, :cols]
             continue
-        if kind == 5:  # W part of Winv (k_winv): -inv(L_pp) L[c0:c0+pn, cs:c0]
-            for q in f.program("chains")[first:first + count]:
-                ld, off = int(q["ld"]), int(q["off"])
-                c0, pn, cs = int(q["c0"]), int(q["pn"]), int(q["cs"])
-                cq = c0 - cs
-                wo = int(q["winv_off"])
-                Wv = dinv[wo:wo + pn * (cq + pn)].reshape(pn, cq + pn)
-                rows = off + np.arange(c0, c0 + pn)[:, None] * ld + np.arange(cs, c0)[None, :]
-                Wv[:, :cq] = -Wv[:, cq:] @ arena[rows]
-            continue
         if kind == 0:
             for q in potrf[first:first + count]:
                 n, ld, off = int(q["n"]), int(q["ld"]), int(q["off"])

@@ -141,13 +141,6 @@ def _access_sets(f):
                 R.append((b, c0, ce, c0, ce))
                 W.append((b, c0, ce, c0, ce))
                 W.append(("wi", b, c0 // pw))      # inverse part of Winv
-        elif kind == 5:
-            for q in chains[first:first + count]:
-                b = bcol_of(q["off"])
-                c0, pn, cs = int(q["c0"]), int(q["pn"]), int(q["cs"])
-                R.append((b, c0, c0 + pn, cs, c0))
-                R.append(("wi", b, c0 // pw))
-                W.append(("ww", b, c0 // pw))      # W part of Winv
         elif kind == 2:
             # exchange: the pack reads, the unpack overwrites whole block columns (engine.cpp
             # pre_exchange / post_exchange)
@@ -297,8 +290,7 @@ def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
     assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert not (launches[:, 6] == 3).any(), "the side stream is not used"
-    eff_cb = max(pw, (max(cb or 64, pw) // pw) * pw)
-    fused = eff_cb == pw and not flags & 512      # fused panel launches replace the chain steps
+    fused = not flags & 512      # fused panel launches replace the chain steps (the chain block knob is ignored)
     assert (launches[:, 0] == (7 if fused else 4)).any() and not (launches[:, 0] == (4 if fused else 7)).any()
     assert ((launches[:, 0] == 6).any()) == bool(flags & 4096), "gather launches only in the deterministic engine"
     if flags & 4096:
@@ -331,9 +323,10 @@ def test_program_variants_agree(flags, cb, monkeypatch):
         monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
-    assert f.program("chain_block") == (cb or 64) // 16 * 16
+    assert f.program("chain_block") == 16          # the chain block is one panel, whatever is asked for
     kinds = f.program("launches")[:, 0]
-    assert (kinds == 7).any() == (cb == 16 and not flags & 512), "fused panel launches: chain block = panel, flag 512 off"
+    assert not (kinds == 5).any()
+    assert (kinds == 7).any() == (not flags & 512), "fused panel launches unless flag 512"
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
@@ -364,7 +357,7 @@ def test_inter_node_updates_are_sliced_over_the_far_stream(flags):
     assert (partial > 0) == (flags == 0)     # K slices only in the default program
     # one event per zone launch, and the chain steps of later levels wait for far-stream events
     far_events = set(int(e) for e in L[L[:, 6] == 2][:, 7] if e >= 0)
-    chain_waits = set(int(w) for w in L[L[:, 0] == 4][:, 8:12].ravel() if w >= 0)
+    chain_waits = set(int(w) for w in L[np.isin(L[:, 0], (4, 7))][:, 8:12].ravel() if w >= 0)   # chain / fused panel steps
     assert len(far_events & chain_waits) >= 3
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
