@@ -655,3 +655,30 @@ def test_solve_dev_on_device_vectors():
     f.solve_dev(y2.data_ptr(), 5, 1, -1)
     f.solve_dev(y2.data_ptr(), 5, 2, -1)
     np.testing.assert_allclose(y2.cpu().numpy()[:, pos].T, got, rtol=1e-12, atol=1e-12)
+
+
+def test_sync_watchdog_reports_where_the_program_stands():
+    """Every blocking wait of the engine has a deadline (SPLLT_HIP_TIMEOUT_S, default 180 s): a
+    device that does not finish makes spllt_wait FAIL (flag -30) with a report of the first
+    launches whose events have not fired, instead of blocking the caller forever.  Exercised with
+    a deadline the factorization cannot meet, in a process of its own (the deadline is read once)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from spllt_amd import api, matgen\n"
+        "from helpers import make_case\n"
+        "f, val = make_case(matgen.nd_like((16, 15, 14), 3), nb=128, nemin=16)\n"
+        "try:\n"
+        "    f.factor(val).wait()\n"
+        "    print('FINISHED')\n"
+        "except api.SplltError as e:\n"
+        "    print('FLAG', e.flag); print(str(e))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, SPLLT_HIP_TIMEOUT_S="0.0000001"))
+    out = r.stdout + r.stderr
+    assert "FLAG -30" in out, out
+    assert "did not drain" in out and "has not finished" in out and "stream 0" in out, out
