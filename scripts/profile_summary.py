@@ -54,8 +54,8 @@ def categorize(f):
         rec = dict(kind=kind, tile=T, flops=float(l[5]), entries=0.0, alg_bytes=0.0, cat="other")
         if kind == 4:
             rec["cat"] = "chain"
-        elif kind == 5:
-            rec["cat"] = "winv"
+        elif kind == 7:
+            rec["cat"] = "panel"      # fused panel step (k_panel)
         elif kind == 6:
             rec["cat"] = "gather"
         elif kind == 1:
