@@ -281,9 +281,6 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
         top_flops = float(df.f.sym_info()["flops"]) - own_w.sum()
     if not args.no_check:
         check = _accuracy_gate(df, A, n, rank, w, True)
-    extra = None
-    if not os.environ.get("SPLLT_NO_BASELINE_CONFIG"):
-        extra = _baseline_config_for(world, args, rank)
     out = None
     if rank == 0:
         out = {
@@ -305,8 +302,35 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
                        "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
                        "subtree_gflop_per_rank": (own_w / 1e9).round(1).tolist(),
                        "top_tree_gflop": round(top_flops / 1e9, 1), "check": check,
-                       "baseline_config_for_this_n": extra},
+                       "baseline_config_for_this_n": None},
         }
+    # The headline measurement is complete.  The configuration BASELINE.json names for this GPU
+    # count is a second, larger distributed factorization: it must not be able to take the
+    # headline with it.  A failure, or no answer within SPLLT_EXTRA_TIMEOUT_S (default 420 s) --
+    # a rank stuck in a collective cannot be interrupted from Python -- makes rank 0 print the
+    # JSON line with the error noted and every rank leave the process.
+    if not os.environ.get("SPLLT_NO_BASELINE_CONFIG"):
+        import json
+        import threading
+        done = threading.Event()
+
+        def leave(why):
+            if rank == 0:
+                out["detail"]["baseline_config_for_this_n"] = {"error": why}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        def guard():
+            if not done.wait(float(os.environ.get("SPLLT_EXTRA_TIMEOUT_S", "420"))):
+                leave("no answer in time: abandoned")
+        threading.Thread(target=guard, daemon=True).start()
+        try:
+            extra = _baseline_config_for(world, args, rank)
+        except BaseException as e:   # noqa: BLE001 - the other ranks follow through their guards
+            leave(repr(e)[:300])
+        done.set()
+        if rank == 0:
+            out["detail"]["baseline_config_for_this_n"] = extra
     return out
 
 
@@ -333,7 +357,8 @@ def _baseline_config_for(world, args, rank):
     si = df.f.sym_info()
     out = {"workload": cfg_name, "n": n, "nb": cfg["nb"], "flops_sym": float(si["flops"]),
            "ms_per_step": round(t * 1e3, 2), "gflops": round(float(si["flops"]) / t / 1e9, 1),
-           "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6}
+           "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
+           "distributed_top_tree": df.dist_top, "exchanges": len(df.plan)}
     df.close()
     del dval
     torch.cuda.empty_cache()
