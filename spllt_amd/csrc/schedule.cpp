@@ -540,7 +540,15 @@ struct Builder {
             const int w = S.bcols[S.node_bcol0[s] + c].width;
             if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pw));
           }
-          int evCH = -1;
+          // "block column final" event: only after the last chunk of the step (what the bulk / far
+          // streams and the level end wait for); it rides on the chunk's last chain-stream launch --
+          // a launch of its own per panel (an event record behind every kernel of the chain)
+          // costs the chain stream ~5 us each
+          int evD = -1;
+          if (la && g + 1 == ng) {
+            evD = P.nevents++;
+            evD_last = evD;
+          }
           if (fuse_c) {
             // the whole panel step in one launch (k_panel): POTRF, the rows below, and the
             // left-looking update of the next panel's columns
@@ -589,7 +597,14 @@ struct Builder {
               L.add_wait(zev(c));    // every inter-node update into block column c
               L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
             }
+            L.record = evD;
             if (L.count > 0) P.launches.push_back(L);
+            else if (evD >= 0) {     // (nothing of this step is ours: the event still has to fire)
+              std::vector<UpdUnit> none;
+              Edge e = edge(ST_CHAIN);
+              e.record = evD;
+              emit_gemm(lev, none, 0.0, false, e);
+            }
           }
           for (int q = 0; !fuse_c && q < maxq; ++q) {
             // (1) chain step: panel q of the sub-tile, one workgroup per node
@@ -637,8 +652,6 @@ struct Builder {
                   L.add_wait(zev(c));    // every inter-node update into block column c
                   L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
                 }
-                evCH = P.nevents++;
-                L.record = evCH;
               }
               if (L.count > 0) P.launches.push_back(L);
             }
@@ -682,20 +695,11 @@ struct Builder {
               P.flops_update += fu;
               fl += ft + fu;
             }
-            if (!us.empty()) {
-              emit_gemm(lev, us, fl, false, edge(ST_CHAIN));
+            {
+              Edge e = edge(ST_CHAIN);
+              e.record = evD;        // (an empty launch still forwards the event)
+              emit_gemm(lev, us, fl, false, e);
             }
-          }
-          // (3) the chunk is final: marker event on the chain stream
-          int evD = -1;
-          if (la) {
-            Launch M;
-            M.kind = L_GEMM; M.level = lev; M.first = 0; M.count = 0; M.tile = 64; M.flops = 0;
-            M.stream = ST_CHAIN;
-            evD = P.nevents++;
-            M.record = evD;
-            P.launches.push_back(M);
-            evD_last = evD;
           }
           // (3b) distributed top tree: the block columns that are final with this chunk go from
           // their owners to everybody (the exchange sits on the chain stream: whatever reads
@@ -805,7 +809,6 @@ struct Builder {
           if (!us_n1.empty()) {
             Edge e = edge(ST_CHAIN);
             if (la) {
-              e.wait0 = evD;
               if (to_next_bcol) {
                 e.wait1 = evB_c1;      // bulk (c-1 -> c+1..) writes the same entries
                 e.wait2 = zev(c + 1);  // and so do the inter-node updates into block column c+1
