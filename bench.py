@@ -320,6 +320,29 @@ def main():
                                   "cancelling row sum (||A|| ||x|| / ||b|| ~ 7e2), so eps * that ratio is the floor")
 
     nlaunch = f.times()["launches"]
+    # reference point for roofline.frac: the tuned library's DGEMM on the update kernel's operand
+    # shapes (C -= A B^T, M = N = 8192) -- what an fp64 GEMM sustains on this box at these K
+    dgemm_ref = None
+    if not args.no_extra_configs:
+        try:
+            dgemm_ref = {"what": "rocBLAS DGEMM through torch.addmm, C(8192 x 8192) -= A(8192 x K) B(8192 x K)^T, TFLOP/s"}
+            for K in (256, 1024):
+                Am = torch.randn(8192, K, dtype=torch.float64, device="cuda")
+                Bm = torch.randn(8192, K, dtype=torch.float64, device="cuda")
+                Cm = torch.zeros(8192, 8192, dtype=torch.float64, device="cuda")
+                best = 1e9
+                for it in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    torch.addmm(Cm, Am, Bm.t(), beta=1.0, alpha=-1.0, out=Cm)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if it >= 2:
+                        best = min(best, e0.elapsed_time(e1))
+                dgemm_ref[f"K{K}"] = round(2.0 * 8192 * 8192 * K / best / 1e9, 2)
+            del Am, Bm, Cm
+        except Exception as e:   # noqa: BLE001 - a reference point, never a reason to lose the line
+            dgemm_ref = {"error": repr(e)[:200]}
     extra = []
     if not args.no_extra_configs and not args.mm and not args.rb and args.scale == 1.0:
         f.close()
@@ -343,7 +366,7 @@ def main():
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
                    "launches": nlaunch, "kernel_table": table, "check": check,
                    "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin,
-                   "configs": extra},
+                   "dgemm_reference": dgemm_ref, "configs": extra},
     }
     print(json.dumps(out))
 

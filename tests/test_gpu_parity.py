@@ -343,6 +343,12 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world, top):
 
 
 @pytest.mark.parametrize("top", ["replicated", "distributed"])
+def test_partitioned_engine_eight_ranks_on_one_gpu(top):
+    """the width the 8-GPU node runs: eight rank-engines on this device, deep top tree"""
+    _run_partitioned(matgen.nd_like((16, 15, 14), 2), 64, 16, 8, None, "mkl", top=top)
+
+
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("name,gen,nb", BIG_CASES)
 def test_config_tile_sizes_partitioned(name, gen, nb, world, top):
