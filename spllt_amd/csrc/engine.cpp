@@ -323,6 +323,10 @@ int Engine::enqueue_program() {
   } else {
     HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
   }
+  // the "last reader" counters of the fused panel launches return to zero by themselves; a
+  // factorization that was cut short (a failed launch, the watchdog) may have left some behind
+  if (!prog_.panel_units.empty())
+    HIPCHK(hipMemsetAsync(d_panel_cnt_, 0, sizeof(int) * 2 * prog_.panel_units.size(), stream_), "memset counters");
   const int big = INT_MAX;
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
