@@ -193,7 +193,9 @@ int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
  * NULL without a HIP device. */
 void *spllt_hip_engine_stream(void *fkeep);
 int spllt_hip_continue(void *fkeep);
-/* "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),
+/* "arena_elems" (int64 x 2: doubles of the factor arena held on this rank's device once its engine
+ * exists - a rank stores only its own branches and the top tree, packed -, doubles of the whole arena),
+ * "owner" (int32 per node: rank or -1 = top tree), "top_bcols" (int32),
  * "top_bcol_owner" (int32 per block column: owner in a distributed top tree, -1 outside it;
  * empty when the top tree is replicated),
  * "map_keep" (uint8 per val->L map entry: scattered on this rank) */
@@ -207,6 +209,7 @@ int spllt_hip_wait(void *fkeep);
 /* copy the whole L arena (block columns concatenated in order) to host memory */
 int spllt_hip_get_factor(void *fkeep, double *out, int64_t count);
 /* device pointer of the L arena (valid until spllt_deallocate_fkeep) */
+/* (partitioned factorization: the rank's packed arena, not the global layout) */
 double *spllt_hip_device_factor(void *fkeep);
 /* timings of the last factorization, milliseconds */
 int spllt_hip_factor_times(void *fkeep, double *submit_ms, double *device_ms, double *h2d_ms,

@@ -296,6 +296,8 @@ class Factorization:
         raw = np.zeros(max(nbytes, 1), dtype=np.uint8)
         self.lib.spllt_hip_partition_get(self.fkeep, name.encode(), raw.ctypes.data, nbytes)
         raw = raw[:nbytes]
+        if name == "arena_elems":
+            return raw.view(np.int64)
         return raw if name == "map_keep" else raw.view(np.int32)
 
     def profile(self, val, in_program=False):

@@ -669,6 +669,10 @@ int64_t spllt_hip_partition_get(void* fkeep, const char* name, void* buf, int64_
     if (buf && bytes) std::memcpy(buf, p, std::min<size_t>(bytes, (size_t)cap));
     return (int64_t)bytes;
   };
+  if (k == "arena_elems") {   // int64 x 2: doubles of the factor arena held on this rank's device, of the whole arena
+    int64_t v[2] = {f->eng ? f->eng->arena_elems() : f->S->arena, f->S->arena};
+    return raw(v, sizeof v);
+  }
   if (k == "owner") return raw(owner.data(), owner.size() * sizeof(int));
   if (k == "top_bcol_owner") {   // empty: the top tree is replicated
     ScheduleOptions so;

@@ -142,6 +142,8 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     }
   }
   build_program(*S_, so, prog_);
+  arena_elems_ = S_->arena;
+  if (opt_.nranks > 1) localize_program();
   upload();
 }
 
@@ -190,11 +192,7 @@ int Engine::upload() {
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
-  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "hipMalloc(L arena)");
-  // partitioned: a factorization clears only the block columns this rank touches
-  // (zero_ranges_); the rest is cleared once, here, and never written
-  if (opt_.nranks > 1)
-    HIPCHK(hipMemset(d_L_, 0, sizeof(double) * (size_t)std::max<int64_t>(1, S.arena)), "memset arena");
+  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, arena_elems_)), "hipMalloc(L arena)");
   HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
   HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)std::max<int64_t>(1, prog_.dinv_size)), "hipMalloc(dinv)");
   if (opt_.nranks > 1) {
@@ -206,9 +204,10 @@ int Engine::upload() {
       const int own = owner_[S.bcols[b].node];
       const bool keep = (own == opt_.rank) || (own < 0 && opt_.rank == 0);
       if (!keep) continue;
+      const int64_t delta = loc_off_[(size_t)b] - S.bcols[b].off;   // (kept block columns are held here)
       for (int64_t i = S.lmap_ptr[b]; i < S.lmap_ptr[b + 1]; ++i) {
         map_keep_[i] = 1;
-        md.push_back(S.map_dst[i]);
+        md.push_back(S.map_dst[i] + delta);
         ms.push_back(S.map_src[i]);
       }
     }
@@ -222,7 +221,10 @@ int Engine::upload() {
   }
   std::vector<int64_t> off(S.nbcol());
   std::vector<int> w(S.nbcol());
-  for (int b = 0; b < S.nbcol(); ++b) { off[b] = S.bcols[b].off; w[b] = S.bcols[b].width; }
+  for (int b = 0; b < S.nbcol(); ++b) {
+    off[b] = loc_off_.empty() ? S.bcols[b].off : loc_off_[(size_t)b];   // (-1: never dereferenced here)
+    w[b] = S.bcols[b].width;
+  }
   HIPCHK(dev_upload(&d_bc_off_, off), "upload bc_off");
   HIPCHK(dev_upload(&d_bc_w_, w), "upload bc_w");
   if (prog_.scratch_size > 0) {
@@ -251,6 +253,46 @@ int Engine::upload() {
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
   HIPCHK(hipHostMalloc((void**)&h_flag_, sizeof(int), hipHostMallocDefault), "hipHostMalloc(flag)");
   return 0;
+}
+
+// Arena offset of the global layout -> this rank's packed arena.  Offsets in the tables are
+// always the base of a block column.
+int64_t Engine::to_local(int64_t g) const {
+  const auto& bc = S_->bcols;
+  size_t lo = 0, hi = bc.size();
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) / 2;
+    if (bc[mid].off <= g) lo = mid; else hi = mid;
+  }
+  if (bc[lo].off != g || loc_off_[lo] < 0) {
+    std::fprintf(stderr, "spllt-hip: internal error: arena offset %lld is not a block column held by rank %d\n",
+                 (long long)g, opt_.rank);
+    return 0;
+  }
+  return loc_off_[lo];
+}
+
+void Engine::localize_program() {
+  const Symbolic& S = *S_;
+  loc_off_.assign((size_t)S.nbcol(), -1);
+  int64_t o = 0;
+  for (int b = 0; b < S.nbcol(); ++b) {
+    const int own = owner_[S.bcols[b].node];
+    if (own != opt_.rank && own >= 0) continue;
+    loc_off_[(size_t)b] = o;
+    o += (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+  }
+  arena_elems_ = o;
+  zero_ranges_.assign(1, {0, o});      // everything held here is cleared per factorization
+  for (UpdUnit& u : prog_.units) {
+    u.a_off = to_local(u.a_off);
+    if (u.mode != MODE_BUFFER) u.d_off = to_local(u.d_off);   // (BUFFER: an offset into the scratch)
+  }
+  for (ChainUnit& u : prog_.chain_units) u.off = to_local(u.off);
+  for (PanelUnit& u : prog_.panel_units) u.off = to_local(u.off);
+  for (GatherTile& t : prog_.gather_tiles) t.d_off = to_local(t.d_off);
+  for (ExchangeItem& it : prog_.xitems)
+    if (it.space == 0) it.off = to_local(it.off);
 }
 
 Engine::~Engine() {
@@ -466,7 +508,20 @@ int Engine::download(double* out, int64_t count) {
   if (status_) return status_;
   if (count > S_->arena) count = S_->arena;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
-  HIPCHK(hipMemcpy(out, d_L_, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost), "L D2H");
+  if (loc_off_.empty()) {
+    HIPCHK(hipMemcpy(out, d_L_, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost), "L D2H");
+    return 0;
+  }
+  // a rank's arena is packed: back into the global layout (zero where nothing is held here)
+  std::vector<double> tmp((size_t)std::max<int64_t>(1, arena_elems_));
+  HIPCHK(hipMemcpy(tmp.data(), d_L_, sizeof(double) * (size_t)arena_elems_, hipMemcpyDeviceToHost), "L D2H");
+  std::memset(out, 0, sizeof(double) * (size_t)count);
+  for (int b = 0; b < S_->nbcol(); ++b) {
+    if (loc_off_[(size_t)b] < 0) continue;
+    const int64_t off = S_->bcols[b].off, cnt = (int64_t)S_->bcols[b].nrow * S_->bcols[b].width;
+    if (off >= count) continue;
+    std::memcpy(out + off, tmp.data() + loc_off_[(size_t)b], sizeof(double) * (size_t)std::min(cnt, count - off));
+  }
   return 0;
 }
 
@@ -474,6 +529,9 @@ int Engine::prepare_solve() {
   if (solve_ready_) return 0;
   const Symbolic& S = *S_;
   build_solve_program(S, prog_.pw, prog_.cb, sprog_, opt_.nranks > 1 ? owner_.data() : nullptr, opt_.rank);
+  if (!loc_off_.empty())
+    for (size_t b = 0; b < sprog_.units.size(); ++b)   // (units of block columns not held here are never launched)
+      if (loc_off_[b] >= 0) sprog_.units[b].off = loc_off_[b];
   HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
   HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
   HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");

@@ -77,6 +77,8 @@ class Engine {
   const std::vector<int>& top_bcols() const { return top_bcols_; }
   const std::vector<char>& map_keep() const { return map_keep_; }
   int not_posdef_column() const { return npd_col_; }
+  // doubles of the factor arena held on this device (a rank of a partition: own branches + top tree)
+  int64_t arena_elems() const { return arena_elems_; }
 
   int download(double* out, int64_t count);  // D2H of the arena
   // spllt_solve on the device-resident factor (x: n x nrhs column-major, original
@@ -136,6 +138,14 @@ class Engine {
   std::vector<std::pair<int64_t, int64_t>> zero_ranges_;  // (offset, count) of the arena this rank clears
   int64_t nmap_ = 0;                // entries of the (filtered) scatter map on the device
   int npd_col_ = -1;
+  // A rank of a partition stores only the block columns it works on (its own branches + the top
+  // tree), packed: loc_off_[b] = offset of block column b in THIS rank's arena (-1: not held
+  // here).  Every table that carries an arena offset is translated after the program is built;
+  // the host-side view (download) stays in the global layout.  Empty: one GPU, arena = global.
+  std::vector<int64_t> loc_off_;
+  int64_t arena_elems_ = 0;          // doubles of the device arena
+  int64_t to_local(int64_t global_off) const;
+  void localize_program();
   FactorStats stats_;
 
   double* d_L_ = nullptr;

@@ -384,6 +384,11 @@ def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None, t
         assert kinds[0] == 1 and kinds[-1] == 3 and kinds.count(2) == nx - 2 >= 1, kinds
         towner = fs[0].partition("top_bcol_owner")
         assert set(towner[towner >= 0].tolist()) == set(range(world))   # every rank owns part of the top tree
+    # a rank's device arena holds only its own branches and the top tree, packed
+    held = np.array([f.partition("arena_elems") for f in fs])
+    top_elems = sum(int(fs[0].sym("bcol_nrow")[b]) * int(fs[0].sym("bcol_width")[b]) for b in fs[0].partition("top_bcols"))
+    assert np.all(held[:, 1] == held[0, 1]) and np.all(held[:, 0] < held[:, 1])
+    assert held[:, 0].sum() == held[0, 1] + (world - 1) * top_elems
     o, rc = oracle_factor(fs[0], val, variant=variant, nthreads=8)
     assert rc == 0
     ref = o.arena()
