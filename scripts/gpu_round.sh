@@ -8,7 +8,8 @@ mkdir -p $OUT
 cd ${GRAFT_REPO_ROOT:-.}
 for i in 1 2; do
   echo "== pytest -m gpu (run $i)" | tee -a $OUT/status_$TAG.txt
-  timeout -k 10 600 python -m pytest tests -m gpu -x -q --timeout 240 > $OUT/pytest_gpu_${TAG}_$i.log 2>&1
+  # (SPLLT_HIP_CRUMBS: the library's last step, should a call never return)
+  SPLLT_HIP_CRUMBS=$OUT/crumbs_${TAG}_$i.txt timeout -k 10 600 python -m pytest tests -m gpu -x -q --timeout 240 > $OUT/pytest_gpu_${TAG}_$i.log 2>&1
   rc=$?; echo "pytest rc=$rc" | tee -a $OUT/status_$TAG.txt; tail -3 $OUT/pytest_gpu_${TAG}_$i.log
   if [ $rc -ne 0 ]; then echo "pytest failed (rc=$rc): stopping"; exit $rc; fi
 done

@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <climits>
 #include <cstdio>
@@ -147,8 +148,70 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   upload();
 }
 
+// Breadcrumbs (SPLLT_HIP_CRUMBS=<file>): the last step the library reached, rewritten at every
+// step.  After a call that never returned (a wedged runtime call cannot be interrupted or traced
+// from the caller) the file names the step.
+static void crumb(const char* what) {
+  static const char* path = std::getenv("SPLLT_HIP_CRUMBS");
+  if (!path || !*path) return;
+  if (FILE* f = std::fopen(path, "w")) {
+    std::fprintf(f, "%s\n", what);
+    std::fclose(f);
+  }
+}
+
+// The HIP streams of the engines are pooled per process: an engine borrows a set (chain, bulk,
+// far) and hands it back drained; streams are created once per (device, CU reservation) and set
+// in use at the same time, never destroyed.  Hundreds of engines per process (the test suite, a
+// solver that re-analyses) then do not create and destroy hundreds of priority / CU-masked
+// streams -- the rare hangs seen on the GPU box sat in runtime calls, not in kernels.
+namespace {
+struct StreamSet {
+  int device, reserve, far_on_bulk;
+  hipStream_t chain, bulk, far;
+  bool in_use;
+};
+std::mutex g_stream_mu;
+std::vector<StreamSet> g_stream_pool;
+}  // namespace
+
+static hipError_t borrow_streams(int device, int reserve, int ncu, bool far_on_bulk, hipStream_t* chain,
+                                 hipStream_t* bulk, hipStream_t* far) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  for (StreamSet& ss : g_stream_pool)
+    if (!ss.in_use && ss.device == device && ss.reserve == reserve && ss.far_on_bulk == (int)far_on_bulk) {
+      ss.in_use = true;
+      *chain = ss.chain; *bulk = ss.bulk; *far = ss.far;
+      return hipSuccess;
+    }
+  int prio_lo = 0, prio_hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (e != hipSuccess) return e;
+  auto masked_stream = [&](hipStream_t* st) -> hipError_t {
+    if (reserve <= 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo);
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int cu = 0; cu < ncu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+  };
+  StreamSet ss{device, reserve, (int)far_on_bulk, nullptr, nullptr, nullptr, true};
+  if ((e = hipStreamCreateWithPriority(&ss.chain, hipStreamNonBlocking, prio_hi)) != hipSuccess) return e;
+  if ((e = masked_stream(&ss.bulk)) != hipSuccess) return e;
+  if (far_on_bulk) ss.far = ss.bulk;
+  else if ((e = masked_stream(&ss.far)) != hipSuccess) return e;
+  g_stream_pool.push_back(ss);
+  *chain = ss.chain; *bulk = ss.bulk; *far = ss.far;
+  return hipSuccess;
+}
+
+static void return_streams(hipStream_t chain) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  for (StreamSet& ss : g_stream_pool)
+    if (ss.chain == chain) ss.in_use = false;
+}
+
 int Engine::upload() {
   const Symbolic& S = *S_;
+  crumb("engine: upload begins");
   // The chain and side streams carry the latency-critical kernels: highest priority, all
   // CUs.  The bulk and far streams carry the updates that run BESIDE a chain: lowest
   // priority and masked off the last `reserve_cus` CUs, so that a chain kernel (one
@@ -157,8 +220,6 @@ int Engine::upload() {
   // launch-to-completion beside a masked bulk kernel, 30 us beside an unmasked one; masking
   // the FIRST bits instead gives erratic 13-450 us).  The wide stream (launches that have
   // the chip to themselves) is not masked.
-  int prio_lo = 0, prio_hi = 0;
-  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");
   if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);
@@ -172,23 +233,16 @@ int Engine::upload() {
   // multiplexes streams onto a handful of hardware queues, and streams that share one
   // serialise (five queues of our own: no overlap at all, 33.0 ms = the serialized 33.2 ms).
   // The wide stream only runs when the chains of a level are done -> chain queue.
-  auto masked_stream = [&](hipStream_t* st) -> hipError_t {
-    if (reserve <= 0) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo);
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int cu = 0; cu < ncu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
-  };
-  HIPCHK(hipStreamCreateWithPriority(&streams_[ST_CHAIN], hipStreamNonBlocking, prio_hi), "hipStreamCreate");
+  crumb("engine: borrowing streams");
+  HIPCHK(borrow_streams(device_, reserve, ncu, std::getenv("SPLLT_FAR_ON_BULK") != nullptr, &streams_[ST_CHAIN],
+                        &streams_[ST_BULK], &streams_[ST_FAR]), "stream creation");
   streams_[ST_WIDE] = streams_[ST_CHAIN];
   streams_[ST_SIDE] = streams_[ST_CHAIN];
-  HIPCHK(masked_stream(&streams_[ST_BULK]), "bulk stream");
-  if (std::getenv("SPLLT_FAR_ON_BULK"))   // experiment: three queues
-    streams_[ST_FAR] = streams_[ST_BULK];
-  else
-    HIPCHK(masked_stream(&streams_[ST_FAR]), "far stream");
   stream_ = streams_[ST_CHAIN];
+  crumb("engine: creating events");
   dag_events_.resize(prog_.nevents);
   for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  crumb("engine: allocating and uploading");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
@@ -252,6 +306,7 @@ int Engine::upload() {
   HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
   HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
   HIPCHK(hipHostMalloc((void**)&h_flag_, sizeof(int), hipHostMallocDefault), "hipHostMalloc(flag)");
+  crumb("engine: ready");
   return 0;
 }
 
@@ -296,8 +351,10 @@ void Engine::localize_program() {
 }
 
 Engine::~Engine() {
+  crumb("engine: destructor, draining streams");
   for (hipStream_t st : streams_)
     if (st) hipStreamSynchronize(st);
+  crumb("engine: destructor, freeing");
   for (auto& e : dag_events_) if (e) hipEventDestroy(e);
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
   hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_panel_); hipFree(d_panel_cnt_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
@@ -307,11 +364,8 @@ Engine::~Engine() {
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   if (ev_h2d_) hipEventDestroy(ev_h2d_);
-  for (int i = 0; i < ST_COUNT; ++i) {
-    bool alias = false;
-    for (int j = 0; j < i; ++j) alias = alias || streams_[j] == streams_[i];
-    if (streams_[i] && !alias) hipStreamDestroy(streams_[i]);
-  }
+  if (streams_[ST_CHAIN]) return_streams(streams_[ST_CHAIN]);   // drained above; back into the pool
+  crumb("engine: destroyed");
 }
 
 int Engine::enqueue_launch(const Launch& l, bool serial) {
@@ -474,10 +528,13 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
   double t0 = now_ms();
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipEventRecord(ev0_, stream_), "event");
+  crumb("factor: H2D of val");
   HIPCHK(hipMemcpyAsync(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream_), "val H2D");
   HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
+  crumb("factor: enqueueing the program");
   int rc = enqueue_program();
   if (rc) return rc;
+  crumb("factor: enqueued");
   HIPCHK(hipEventRecord(ev1_, stream_), "event");
   pending_ = true;
   stats_.submit_ms = now_ms() - t0;
@@ -487,12 +544,14 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
 int Engine::wait() {
   if (status_) return status_;
   if (!pending_) return 0;
+  crumb("wait: polling the chain stream");
   if (awaiting_exchange_) return sync_phase();  // not finished: only drain phase 1
   {
     int rc = sync_stream(stream_, "stream sync");
     if (rc) return rc;
   }
   pending_ = false;
+  crumb("wait: done");
   float ms = 0;
   if (hipEventElapsedTime(&ms, ev0_, ev1_) == hipSuccess) stats_.device_ms = ms;
   if (hipEventElapsedTime(&ms, ev0_, ev_h2d_) == hipSuccess) stats_.h2d_ms = ms;

@@ -102,6 +102,37 @@ __device__ inline void st_c(double* M, int row0, int col0, int lane, d4 c) {
   for (int r = 0; r < 4; ++r) M[(row0 + lq + 4 * r) * TLD + col0 + lr] = c[r];
 }
 
+// broadcast of lane K of every row of 16 lanes to the lanes of that row, in the vector ALU
+// (DPP row_newbcast: no trip through the scalar registers, no SALU/VALU hazard waits).  The
+// register Cholesky keeps four identical copies of its 16 x 16 block, one per row of lanes, so
+// this is the broadcast of lane K of the wave.
+template <int K>
+__device__ __forceinline__ double bcast_row(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// (src is a compile-time constant once the caller's loops are unrolled: the switch folds away)
+__device__ __forceinline__ double bcast16(double v, int src) {
+  switch (src) {
+    case 0: return bcast_row<0>(v);
+    case 1: return bcast_row<1>(v);
+    case 2: return bcast_row<2>(v);
+    case 3: return bcast_row<3>(v);
+    case 4: return bcast_row<4>(v);
+    case 5: return bcast_row<5>(v);
+    case 6: return bcast_row<6>(v);
+    case 7: return bcast_row<7>(v);
+    case 8: return bcast_row<8>(v);
+    case 9: return bcast_row<9>(v);
+    case 10: return bcast_row<10>(v);
+    case 11: return bcast_row<11>(v);
+    case 12: return bcast_row<12>(v);
+    case 13: return bcast_row<13>(v);
+    case 14: return bcast_row<14>(v);
+    default: return bcast_row<15>(v);
+  }
+}
 // broadcast of lane `src` (compile-time constant after unrolling) through SGPRs
 __device__ inline double bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -148,29 +179,32 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
   const int np = nblk * 16;
   const bool do_chol = !(u.flags & 1);
   STAMP(0);
-  // identity-padded lower triangle: thread t owns 16 consecutive columns of row t/4
+  // identity-padded lower triangle into LDS.  Lane l of wave w takes column l of the rows
+  // w, w+4, w+8, ...: one wave-instruction reads one whole row (4 cache lines; the earlier
+  // mapping -- 16 consecutive columns per thread -- touched 64 lines per instruction and spent
+  // 7.8 k of the kernel's 55 k cycles loading, 7.5 k storing).
   // (callers may run more than 256 threads: only the first 256 load / store / compute here,
   // the others just take part in the barriers)
-  const int li = tid >> 2, lj0 = (tid & 3) * 16;
-  if (li < 64) {
+  const int lw = tid >> 6, lc = tid & 63;
+  if (tid < 256) {
     // unconditional loads at clamped addresses (all 16 in flight at once; a load under a
     // condition is compiled into a branch with its own wait), selection afterwards
     double v[16];
-    const double* arow = A + (int64_t)(li < n ? li : n - 1) * ld;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = arow[lj0 + e < n ? lj0 + e : n - 1];
+    const int cc = lc < n ? lc : n - 1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int j = lj0 + e;
-      v[e] = (li < n && j <= li) ? v[e] : ((li == j) ? 1.0 : 0.0);
+      const int r = 4 * e + lw;
+      v[e] = A[(int64_t)(r < n ? r : n - 1) * ld + cc];
     }
     // all 64 rows are written: the matrix-core steps of the callers read whole
     // 16-row fragments of X, and stale LDS may hold NaN bit patterns
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      T[li * TLD + lj0 + e] = v[e];
-      X[li * TLD + lj0 + e] = 0.0;
-      if (!do_chol && lj0 + e == li) RI[li] = 1.0 / v[e];
+      const int r = 4 * e + lw;
+      const double x = (r < n && lc <= r) ? v[e] : ((r == lc) ? 1.0 : 0.0);
+      T[r * TLD + lc] = x;
+      X[r * TLD + lc] = 0.0;
+      if (!do_chol && lc == r) RI[r] = 1.0 / x;
     }
   }
   __syncthreads();
@@ -216,8 +250,8 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
         // reciprocal square root, so the readlanes overlap its latency
         double tk[16];
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) tk[k] = bcast(row[j], k);
-        double djj = bcast(row[j], j);
+        for (int k = j + 1; k < 16; ++k) tk[k] = bcast16(row[j], k);
+        double djj = bcast16(row[j], j);
         if (!(djj > 0.0)) {
           if (failcol == (1 << 30)) failcol = j;
           djj = 1.0;
@@ -319,14 +353,14 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
   STAMP(15);
   // flags bit 1: the caller stores L itself; bit 2: redundant copy, neither the inverse is
   // stored nor a failed pivot reported
-  if (li < n) {
+  if (tid < 256 && lc < n) {
     const bool st_l = do_chol && !(u.flags & 2), st_i = !(u.flags & 4);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int j = lj0 + e;
-      if (j < n) {
-        if (st_l && j <= li) A[(int64_t)li * ld + j] = T[li * TLD + j];
-        if (st_i) D[(int64_t)li * ldd + j] = X[li * TLD + j];
+      const int r = 4 * e + lw;
+      if (r < n) {
+        if (st_l && lc <= r) A[(int64_t)r * ld + lc] = T[r * TLD + lc];
+        if (st_i) D[(int64_t)r * ldd + lc] = X[r * TLD + lc];
       }
     }
   }
@@ -463,13 +497,11 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
   potrf64_body(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? 2 : 6, flag);
   __syncthreads();
   if (last_reader(counters + 2 * tl.unit, u.ntile, &vote)) {
-    const int li = tid >> 3, lj0 = (tid & 7) * 8;
-    if (li < pn) {
+    const int lc = tid & 63;       // a wave-instruction writes (part of) one row
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int j = lj0 + e;
-        if (j <= li) Dg[(int64_t)li * ld + j] = sh.T[li * TLD + j];
-      }
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * e + (tid >> 6);
+      if (r < pn && lc <= r) Dg[(int64_t)r * ld + lc] = sh.T[r * TLD + lc];
     }
     __syncthreads();
   }
