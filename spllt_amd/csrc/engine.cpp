@@ -203,6 +203,36 @@ static hipError_t borrow_streams(int device, int reserve, int ncu, bool far_on_b
   return hipSuccess;
 }
 
+// ... and so are the dependency events of the programs (a few hundred per engine, no timing).
+// An event taken from the pool may carry the record of an earlier engine: waiting for it is a
+// no-op, exactly like waiting for an event that was never recorded.
+static std::vector<std::vector<hipEvent_t>> g_event_pool;   // per device
+
+static hipError_t borrow_events(std::vector<hipEvent_t>& out, size_t n, int device) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if ((int)g_event_pool.size() <= device) g_event_pool.resize((size_t)device + 1);
+  std::vector<hipEvent_t>& pool = g_event_pool[(size_t)device];
+  out.assign(n, nullptr);
+  for (size_t i = 0; i < n; ++i) {
+    if (!pool.empty()) {
+      out[i] = pool.back();
+      pool.pop_back();
+    } else {
+      hipError_t e = hipEventCreateWithFlags(&out[i], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}
+
+static void return_events(std::vector<hipEvent_t>& ev, int device) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if ((int)g_event_pool.size() <= device) g_event_pool.resize((size_t)device + 1);
+  for (hipEvent_t e : ev)
+    if (e) g_event_pool[(size_t)device].push_back(e);
+  ev.clear();
+}
+
 static void return_streams(hipStream_t chain) {
   std::lock_guard<std::mutex> lk(g_stream_mu);
   for (StreamSet& ss : g_stream_pool)
@@ -240,8 +270,7 @@ int Engine::upload() {
   streams_[ST_SIDE] = streams_[ST_CHAIN];
   stream_ = streams_[ST_CHAIN];
   crumb("engine: creating events");
-  dag_events_.resize(prog_.nevents);
-  for (auto& e : dag_events_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  HIPCHK(borrow_events(dag_events_, (size_t)prog_.nevents, device_), "hipEventCreate");
   crumb("engine: allocating and uploading");
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
@@ -355,7 +384,7 @@ Engine::~Engine() {
   for (hipStream_t st : streams_)
     if (st) hipStreamSynchronize(st);
   crumb("engine: destructor, freeing");
-  for (auto& e : dag_events_) if (e) hipEventDestroy(e);
+  return_events(dag_events_, device_);       // (the streams are drained: nothing refers to them any more)
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
   hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_panel_); hipFree(d_panel_cnt_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
   hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
