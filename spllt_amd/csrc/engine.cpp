@@ -34,6 +34,51 @@ int Engine::fail(int code, const char* what, hipError_t e) {
   return code;
 }
 
+// Tables of an engine go to the device as ONE allocation and ONE copy: the parts are laid out in
+// a host staging buffer (256-byte aligned), the typed device pointers are set after the upload.
+// (Two dozen allocations, synchronous copies and frees per engine were two dozen chances per
+// engine to sit in the runtime.)
+struct TableStager {
+  struct Slot { void** dptr; size_t off; };
+  std::vector<char> host;
+  std::vector<Slot> slots;
+  template <class Tp>
+  void add(Tp** dptr, const Tp* src, size_t count) {
+    const size_t off = (host.size() + 255) / 256 * 256;
+    const size_t bytes = std::max<size_t>(count * sizeof(Tp), 8);
+    host.resize(off + bytes, 0);
+    if (count) std::memcpy(host.data() + off, src, count * sizeof(Tp));
+    slots.push_back({(void**)dptr, off});
+  }
+  template <class Tp>
+  void add(Tp** dptr, const std::vector<Tp>& v) { add(dptr, v.data(), v.size()); }
+  hipError_t commit(char** blob) {
+    hipError_t e = hipMalloc((void**)blob, std::max<size_t>(host.size(), 8));
+    if (e != hipSuccess) return e;
+    if (!host.empty()) e = hipMemcpy(*blob, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    for (const Slot& sl : slots) *sl.dptr = *blob + sl.off;
+    return hipSuccess;
+  }
+};
+
+// pinned words for the "not positive definite" flag, pooled per process
+static std::vector<int*> g_pinned_words;
+static std::mutex g_pinned_mu;
+static hipError_t borrow_pinned_word(int** p) {
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  if (!g_pinned_words.empty()) {
+    *p = g_pinned_words.back();
+    g_pinned_words.pop_back();
+    return hipSuccess;
+  }
+  return hipHostMalloc((void**)p, sizeof(int), hipHostMallocDefault);
+}
+static void return_pinned_word(int* p) {
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  if (p) g_pinned_words.push_back(p);
+}
+
 int Engine::sync_stream(hipStream_t st, const char* what) {
   static const double limit_s = [] {
     const char* e = std::getenv("SPLLT_HIP_TIMEOUT_S");
@@ -308,33 +353,34 @@ int Engine::upload() {
     off[b] = loc_off_.empty() ? S.bcols[b].off : loc_off_[(size_t)b];   // (-1: never dereferenced here)
     w[b] = S.bcols[b].width;
   }
-  HIPCHK(dev_upload(&d_bc_off_, off), "upload bc_off");
-  HIPCHK(dev_upload(&d_bc_w_, w), "upload bc_w");
+  TableStager tab;
+  tab.add(&d_bc_off_, off);
+  tab.add(&d_bc_w_, w);
+  std::vector<UpdUnit> units;    // (outlives the staging copy below)
   if (prog_.scratch_size > 0) {
     HIPCHK(hipMalloc((void**)&d_scratch_, sizeof(double) * (size_t)prog_.scratch_size), "hipMalloc(scratch)");
     // MODE_BUFFER units address the scratch relative to the arena pointer like every other unit
-    std::vector<UpdUnit> units(prog_.units);
+    units = prog_.units;
     const int64_t shift = d_scratch_ - d_L_;
     for (UpdUnit& u : units)
       if (u.mode == MODE_BUFFER) u.d_off += shift;
-    HIPCHK(dev_upload(&d_units_, units), "upload units");
+    tab.add(&d_units_, units);
   } else {
-    HIPCHK(dev_upload(&d_units_, prog_.units), "upload units");
+    tab.add(&d_units_, prog_.units);
   }
-  HIPCHK(dev_upload(&d_gtiles_, prog_.gather_tiles), "upload gather tiles");
-  HIPCHK(dev_upload(&d_gitems_, prog_.gather_items), "upload gather items");
-  HIPCHK(dev_upload(&d_tiles_, prog_.tiles), "upload tiles");
-  HIPCHK(dev_upload(&d_chain_, prog_.chain_units), "upload chain units");
-  HIPCHK(dev_upload(&d_panel_, prog_.panel_units), "upload panel units");
-  {
-    const size_t bytes = sizeof(int) * 2 * std::max<size_t>(1, prog_.panel_units.size());
-    HIPCHK(hipMalloc((void**)&d_panel_cnt_, bytes), "hipMalloc(panel counters)");
-    HIPCHK(hipMemset(d_panel_cnt_, 0, bytes), "memset(panel counters)");
-  }
-  HIPCHK(dev_upload(&d_relpos_, prog_.relpos), "upload relpos");
-  HIPCHK(dev_upload(&d_rlist_, S.rlist), "upload rlist");
-  HIPCHK(hipMalloc((void**)&d_flag_, sizeof(int)), "hipMalloc(flag)");
-  HIPCHK(hipHostMalloc((void**)&h_flag_, sizeof(int), hipHostMallocDefault), "hipHostMalloc(flag)");
+  tab.add(&d_gtiles_, prog_.gather_tiles);
+  tab.add(&d_gitems_, prog_.gather_items);
+  tab.add(&d_tiles_, prog_.tiles);
+  tab.add(&d_chain_, prog_.chain_units);
+  tab.add(&d_panel_, prog_.panel_units);
+  const std::vector<int> zeros(2 * std::max<size_t>(1, prog_.panel_units.size()), 0);
+  tab.add(&d_panel_cnt_, zeros);
+  tab.add(&d_relpos_, prog_.relpos);
+  tab.add(&d_rlist_, S.rlist);
+  const int big_flag = INT_MAX;
+  tab.add(&d_flag_, &big_flag, 1);
+  HIPCHK(tab.commit(&d_tables_), "upload tables");
+  HIPCHK(borrow_pinned_word(&h_flag_), "hipHostMalloc(flag)");
   crumb("engine: ready");
   return 0;
 }
@@ -386,10 +432,11 @@ Engine::~Engine() {
   crumb("engine: destructor, freeing");
   return_events(dag_events_, device_);       // (the streams are drained: nothing refers to them any more)
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_bc_off_); hipFree(d_bc_w_); hipFree(d_units_); hipFree(d_tiles_); hipFree(d_chain_); hipFree(d_panel_); hipFree(d_panel_cnt_); hipFree(d_gtiles_); hipFree(d_gitems_); hipFree(d_scratch_);
-  hipFree(d_sunits_); hipFree(d_slist_); hipFree(d_stiles_); hipFree(d_y_);
-  hipFree(d_relpos_); hipFree(d_rlist_); hipFree(d_flag_);
-  if (h_flag_) hipHostFree(h_flag_);
+  hipFree(d_scratch_);
+  hipFree(d_tables_);         // bc_off, bc_w, units, tiles, chain / panel units, counters, gather tables, relpos, rlist, flag
+  hipFree(d_solve_tables_);   // solve units, list, tiles
+  hipFree(d_y_);
+  return_pinned_word(h_flag_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   if (ev_h2d_) hipEventDestroy(ev_h2d_);
@@ -620,9 +667,13 @@ int Engine::prepare_solve() {
   if (!loc_off_.empty())
     for (size_t b = 0; b < sprog_.units.size(); ++b)   // (units of block columns not held here are never launched)
       if (loc_off_[b] >= 0) sprog_.units[b].off = loc_off_[b];
-  HIPCHK(dev_upload(&d_sunits_, sprog_.units), "upload solve units");
-  HIPCHK(dev_upload(&d_slist_, sprog_.diag_list), "upload solve list");
-  HIPCHK(dev_upload(&d_stiles_, sprog_.tiles), "upload solve tiles");
+  {
+    TableStager tab;
+    tab.add(&d_sunits_, sprog_.units);
+    tab.add(&d_slist_, sprog_.diag_list);
+    tab.add(&d_stiles_, sprog_.tiles);
+    HIPCHK(tab.commit(&d_solve_tables_), "upload solve tables");
+  }
   HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
   solve_ready_ = true;
   return 0;

@@ -155,6 +155,8 @@ class Engine {
   int64_t* d_map_src_ = nullptr;
   int64_t* d_bc_off_ = nullptr;
   int* d_bc_w_ = nullptr;
+  char* d_tables_ = nullptr;        // one allocation behind the table pointers below
+  char* d_solve_tables_ = nullptr;  // ... and behind the solve tables
   UpdUnit* d_units_ = nullptr;
   UpdTile* d_tiles_ = nullptr;
   ChainUnit* d_chain_ = nullptr;
