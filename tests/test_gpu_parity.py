@@ -693,3 +693,33 @@ def test_sync_watchdog_reports_where_the_program_stands():
     out = r.stdout + r.stderr
     assert "FLAG -30" in out, out
     assert "did not drain" in out and "has not finished" in out and "stream 0" in out, out
+
+
+def test_bench_contract_one_gpu():
+    """`python bench.py` on a shrunken workload: ONE JSON line with the driver's fields, the
+    roofline object (dominant kernel, alone and inside the program) and the CPU baseline of the
+    oracle on the same workload; the accuracy gate inside must pass."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--scale", "0.5", "--no-extra-configs"], capture_output=True, text=True, timeout=280,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["unit"] == "GFLOP/s" and d["value"] > 0 and "workload" in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 78.6
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac_in_program"] <= 1
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    chk = d["detail"]["check"]
+    assert chk["bwd_err"] <= 1e-14 and chk["max_relerr_L_vs_cpu"] <= 1e-12

@@ -209,3 +209,32 @@ def test_run_exchange_calls_on_rccl_single_rank():
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, 33500 + (os.getpid() % 2000), ret), nprocs=1, join=True)
     assert ret.get(0) is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist_top", ["0", "1"])
+def test_bench_contract_two_ranks_over_gloo(dist_top):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per
+    process), rehearsed on the one-GPU box: both ranks on device 0, gloo instead of RCCL.  Rank 0
+    must print ONE JSON line with the contract's fields, `value` from the width-2 run, and a
+    residual that passes; with the top tree replicated and distributed."""
+    import json
+    import subprocess
+    port = 34500 + (os.getpid() % 2000) + (5 if dist_top == "1" else 0)
+    env = dict(os.environ, SPLLT_DIST_BACKEND="gloo", SPLLT_SINGLE_DEVICE="1", SPLLT_NO_BASELINE_CONFIG="1",
+               SPLLT_DIST_TOP=dist_top)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--scale", "0.5"], capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["value"] > 0 and d["detail"]["partition_width"] == 2
+    assert d["detail"]["distributed_top_tree"] == (dist_top == "1")
+    assert d["detail"]["check"]["bwd_err"] <= 1e-14
