@@ -342,6 +342,14 @@ def test_partitioned_engine_two_ranks_on_one_gpu(world, top):
     _run_partitioned(matgen.nd_like((10, 9, 8), 2), 32, 8, world, 16, "plain", top=top)
 
 
+@pytest.mark.parametrize("extra", [2, 4096, 512, 64], ids=["single-stream", "deterministic", "unfused", "no-slices"])
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
+def test_partitioned_engine_variants(top, extra):
+    """the partitioned program in the engine's other variants (single stream, deterministic
+    assembly, no fused panel launches, no early slices), top tree replicated and distributed"""
+    _run_partitioned(matgen.nd_like((12, 11, 10), 2), 48, 8, 3, 16, "plain", top=top, extra_flags=extra)
+
+
 @pytest.mark.parametrize("top", ["replicated", "distributed"])
 def test_partitioned_engine_eight_ranks_on_one_gpu(top):
     """the width the 8-GPU node runs: eight rank-engines on this device, deep top tree"""
@@ -356,12 +364,12 @@ def test_config_tile_sizes_partitioned(name, gen, nb, world, top):
     _run_partitioned(gen(), nb, 32, world, None, "mkl", check_multicolumn=nb, top=top)
 
 
-def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None, top="replicated"):
+def _run_partitioned(A, nb, nemin, world, pw, variant, check_multicolumn=None, top="replicated", extra_flags=0):
     torch = _torch()
     fs, bufs = [], []
     for r in range(world):
         f, val = make_case(A, nb=nb, nemin=nemin, prune=True, ncpu=world, panel_width=pw,
-                           engine_flags=DIST_TOP[top])
+                           engine_flags=DIST_TOP[top] | extra_flags)
         if check_multicolumn:
             _assert_multicolumn(f, check_multicolumn)
         xel = f.set_partition(r, world)
