@@ -598,13 +598,10 @@ struct Builder {
               L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
             }
             L.record = evD;
-            if (L.count > 0) P.launches.push_back(L);
-            else if (evD >= 0) {     // (nothing of this step is ours: the event still has to fire)
-              std::vector<UpdUnit> none;
-              Edge e = edge(ST_CHAIN);
-              e.record = evD;
-              emit_gemm(lev, none, 0.0, false, e);
-            }
+            // (a rank that owns nothing of this step still carries its waits and its event: what
+            // follows on the other streams is ordered behind the updates into block column c
+            // through them)
+            if (L.count > 0 || L.record >= 0 || L.wait[0] >= 0) P.launches.push_back(L);
           }
           for (int q = 0; !fuse_c && q < maxq; ++q) {
             // (1) chain step: panel q of the sub-tile, one workgroup per node
@@ -653,7 +650,7 @@ struct Builder {
                   L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
                 }
               }
-              if (L.count > 0) P.launches.push_back(L);
+              if (L.count > 0 || L.wait[0] >= 0) P.launches.push_back(L);   // (no unit of ours: the waits stay)
             }
             // (2) rows below the panel: X = A(:, c0:c0+pn) inv(L_pp)^T
             double fl = 0;

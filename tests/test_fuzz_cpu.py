@@ -54,7 +54,7 @@ def test_fuzz_program_single_gpu(seed, monkeypatch):
     assert _dag_is_ordered(f), (nb, pw, nemin, flags, cb)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_fuzz_program_partitioned(seed):
     rng = np.random.default_rng(4000 + seed)
     A = _matrix(rng, seed)
@@ -62,7 +62,7 @@ def test_fuzz_program_partitioned(seed):
     nb = int(rng.choice([8, 16, 32, 48]))
     pw = int(rng.choice([8, 16, 24]))
     # top tree replicated on every rank / distributed over the ranks (owner computes)
-    flags = int(rng.choice([8192, 16384]))
+    flags = int(rng.choice([8192, 16384])) | int(rng.choice([0, 0, 2, 64, 512, 1024, 2048, 4096]))   # ... in any engine variant
     fs, vals = [], None
     for r in range(world):
         f, vals = make_case(A, nb=nb, nemin=8, prune=True, ncpu=world, panel_width=pw, engine_flags=flags)
