@@ -131,7 +131,8 @@ def test_fuzz_partitioned_factor_and_solve(seed):
     nb = int(rng.choice([8, 16, 32, 48, 100]))
     pw = int(rng.choice([8, 16, 24, 64]))
     nemin = int(rng.choice([4, 16, 32]))
-    flags = int(rng.choice([8192, 16384]))      # top tree distributed over the ranks / replicated
+    # top tree distributed over the ranks / replicated, in any engine variant
+    flags = int(rng.choice([8192, 16384])) | int(rng.choice([0, 0, 2, 64, 512, 1024, 2048, 4096]))
     fs, val, got, B = _partitioned_factor_and_solve(A, world, nb, nemin, pw, flags)
     o, rc = oracle_factor(fs[0], val)
     assert rc == 0
