@@ -689,7 +689,7 @@ def test_sync_watchdog_reports_where_the_program_stands():
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "from spllt_amd import api, matgen\n"
         "from helpers import make_case\n"
-        "f, val = make_case(matgen.nd_like((16, 15, 14), 3), nb=128, nemin=16)\n"
+        "f, val = make_case(matgen.nd_like((24, 22, 20), 3), nb=128, nemin=16)\n"
         "try:\n"
         "    f.factor(val).wait()\n"
         "    print('FINISHED')\n"
@@ -700,7 +700,10 @@ def test_sync_watchdog_reports_where_the_program_stands():
                        env=dict(os.environ, SPLLT_HIP_TIMEOUT_S="0.0000001"))
     out = r.stdout + r.stderr
     assert "FLAG -30" in out, out
-    assert "did not drain" in out and "has not finished" in out and "stream 0" in out, out
+    assert "did not drain" in out and "stream 0" in out, out
+    # (the launches that have not finished are listed -- unless the device got through the small
+    # factorization between the missed deadline and the report, which then says the streams are idle)
+    assert "has not finished" in out or "stream 0 idle" in out, out
 
 
 def test_bench_contract_one_gpu():
