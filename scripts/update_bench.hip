@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
   for (int K : {64, 128, 256, 512, 1024}) {
     const int64_t src_elems = (int64_t)(M + N) * K, dst_elems = (int64_t)M * N;
     double* L;
-    hipMalloc(&L, (src_elems + dst_elems) * 8);
+    hipMalloc(&L, (src_elems + dst_elems + 64) * 8);
     std::vector<double> h(src_elems);
     for (int64_t i = 0; i < src_elems; ++i) h[i] = ((i * 2654435761u) % 1000) * 1e-3 - 0.5;
     hipMemcpy(L, h.data(), src_elems * 8, hipMemcpyHostToDevice);

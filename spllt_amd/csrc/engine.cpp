@@ -320,9 +320,11 @@ int Engine::upload() {
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
-  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)std::max<int64_t>(1, arena_elems_)), "hipMalloc(L arena)");
+  // (+ 32 doubles: the update kernel loads whole 16-column chunks, the last one of a ragged K
+  // window reaches past the block column's end)
+  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)(std::max<int64_t>(1, arena_elems_) + 32)), "hipMalloc(L arena)");
   HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
-  HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)std::max<int64_t>(1, prog_.dinv_size)), "hipMalloc(dinv)");
+  HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMalloc(dinv)");
   if (opt_.nranks > 1) {
     // this rank scatters A only into its own subtrees; the top tree's values
     // are contributed by rank 0 alone so that the cross-rank sum holds them once

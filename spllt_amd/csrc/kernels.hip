@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "kernels.hpp"
 
@@ -875,6 +876,255 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   }
 }
 
+template <int T, int WM, int WN>
+__device__ __forceinline__ void update_dma_body(const UpdTile* __restrict__ tiles,
+                                                const UpdUnit* __restrict__ units,
+                                                const int64_t* __restrict__ bc_off,
+                                                const int* __restrict__ bc_w,
+                                                double* __restrict__ L,
+                                                const int* __restrict__ relpos,
+                                                const int* __restrict__ rlist,
+                                                const double* __restrict__ dinv, int prio) {
+  // latency-critical launches (panel chain) outrank the trailing-update waves
+  // they share a SIMD with
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  constexpr int BK = 16;
+  constexpr int NT = 64 * WM * WN;    // threads: WM x WN waves, 16 tile rows per wave
+  static_assert(T == 16 * WM * WN, "one wave stages 16 rows of each operand tile per step");
+  constexpr int FMM = T / WM / 16;    // MFMA fragments per wave, rows
+  constexpr int FMN = T / WN / 16;    // MFMA fragments per wave, columns
+  constexpr int ROWB = BK * 8;        // bytes of a tile row in LDS: 128, no padding
+  // two stages of [A tile | B tile], rows of 128 bytes whose eight 16-byte chunks are stored
+  // XOR-swizzled by (row >> 1) & 7: the DMA writes whole 1 KB runs, the MFMA operand reads
+  // (16 rows x one k) still hit 32 different bank pairs
+  extern __shared__ __attribute__((aligned(16))) double upd_smem[];
+  char* const smem = reinterpret_cast<char*>(upd_smem);
+
+  const UpdTile tl = tiles[blockIdx.x];
+  const UpdUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int i0 = tl.ti * T, j0 = tl.tj * T;
+  const int M = u.M, N = u.N;
+
+  // DMA mapping: instruction i (0, 1) of wave w fills tile rows (2w + i) * 8 + (lane >> 3), LDS
+  // chunk lane & 7 of that row, which holds the row's global chunk (lane & 7) ^ ((row >> 1) & 7).
+  // Rows beyond the tile edge re-read the last valid row (their results are never stored).
+  // (recomputed at every segment switch rather than kept in registers)
+  auto dma_row = [&](int i) { return (2 * wave + i) * 8 + (lane >> 3); };
+
+  d4 acc[FMM][FMN];
+#pragma unroll
+  for (int a = 0; a < FMM; ++a)
+#pragma unroll
+    for (int b = 0; b < FMN; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // ---- K-segment state -----------------------------------------------------
+  int seg = 0, kk = 0, klen = 0;
+  const double* aptr[2] = {nullptr, nullptr};
+  const double* bptr[2] = {nullptr, nullptr};
+  // width / offset of the NEXT K segment, requested one segment ahead so that a
+  // segment switch does not stall on two dependent table loads
+  int nxt_w = 0;
+  int64_t nxt_off = 0;
+  auto seg_setup = [&](int sg) {
+    const int bcol = u.src_bcol0 + sg;
+    // segment 0 comes with the unit: one dependent lookup less before the first loads
+    const int w = sg == 0 ? u.a_w : nxt_w;
+    const int64_t base = sg == 0 ? u.a_off : nxt_off;
+    if (sg + 1 < u.nseg) {
+      nxt_w = bc_w[bcol + 1];
+      nxt_off = bc_off[bcol + 1];
+    }
+    const int rshift = u.seg_r0 + sg * u.seg_stride;
+    const int kbeg = (u.nseg == 1) ? u.k0 : 0;
+    klen = (u.nseg == 1 && u.klen >= 0) ? u.klen : w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = dma_row(i);
+      const int rA = min(i0 + row, M - 1), rB = min(j0 + row, N - 1);
+      const int cgl = 2 * ((lane & 7) ^ ((row >> 1) & 7));     // swizzled chunk, in doubles
+      aptr[i] = L + base + (int64_t)(u.src_r0 + rA - rshift) * w + kbeg + cgl;
+      if (u.mode == MODE_TRSM) {
+        bptr[i] = dinv + u.dinv_off + (int64_t)rB * u.dinv_ld + cgl;
+      } else if (u.b_bcol0 >= 0) {
+        const int bb = u.b_bcol0 + sg;
+        const int64_t ldb = bc_w[bb];
+        bptr[i] = L + bc_off[bb] + (int64_t)(u.src_c0 + rB - (u.b_seg_r0 + sg * u.seg_stride)) * ldb + kbeg + cgl;
+      } else {
+        bptr[i] = L + base + (int64_t)(u.src_c0 + rB - rshift) * w + kbeg + cgl;
+      }
+    }
+  };
+  // one K step (16 columns from kk of the current segment) of both tiles straight into stage st;
+  // a ragged last chunk of a segment is loaded whole (what lies behind the window is some other
+  // part of the arena: the allocations carry slack) and cleared in LDS afterwards (clear_tail)
+  auto issue = [&](int st) {
+    char* base = smem + st * (2 * T * ROWB);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[i] + kk),
+                                       (__attribute__((address_space(3))) void*)(base + (2 * wave + i) * 8 * ROWB),
+                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr[i] + kk),
+                                       (__attribute__((address_space(3))) void*)(base + T * ROWB + (2 * wave + i) * 8 * ROWB),
+                                       16, 0, 0);
+    }
+  };
+  auto clear_tail = [&](int st, int rem) {     // columns >= rem of the step in stage st become zero
+    char* base = smem + st * (2 * T * ROWB);
+    for (int e = tid; e < 2 * T * BK; e += NT) {
+      const int row = e >> 4, kc = e & 15;
+      if (kc >= rem)
+        *(double*)(base + row * ROWB + (((kc >> 1) ^ (((row & (T - 1)) >> 1) & 7)) << 4) + ((kc & 1) << 3)) = 0.0;
+    }
+  };
+  // advance to the next K step (possibly the next K segment); false: none left
+  auto advance = [&]() {
+    kk += BK;
+    if (kk < klen) return true;
+    while (seg + 1 < u.nseg) {
+      seg_setup(++seg);
+      kk = 0;
+      if (klen > 0) return true;
+    }
+    return false;
+  };
+  auto mfma_step = [&](int st) {
+    const char* As = smem + st * (2 * T * ROWB);
+    const char* Bs = As + T * ROWB;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      double af[FMM], bf[FMN];
+      const int kq = 4 * ks + lq, cg = kq >> 1, half = kq & 1;
+#pragma unroll
+      for (int a = 0; a < FMM; ++a) {
+        const int row = wm * (T / WM) + a * 16 + lr;
+        af[a] = *(const double*)(As + row * ROWB + ((cg ^ ((row >> 1) & 7)) << 4) + (half << 3));
+      }
+#pragma unroll
+      for (int b = 0; b < FMN; ++b) {
+        const int row = wn * (T / WN) + b * 16 + lr;
+        bf[b] = *(const double*)(Bs + row * ROWB + ((cg ^ ((row >> 1) & 7)) << 4) + (half << 3));
+      }
+#pragma unroll
+      for (int a = 0; a < FMM; ++a)
+#pragma unroll
+        for (int b = 0; b < FMN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  seg_setup(0);
+  while (klen <= 0 && seg + 1 < u.nseg) seg_setup(++seg);
+  bool more = klen > 0;
+  if (more) {
+    issue(0);
+    int rem = klen - kk;                       // valid columns of the step in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (rem < BK) { clear_tail(0, rem); __syncthreads(); }
+    int st = 0;
+    while (true) {
+      // stage st holds step k; step k+1 is requested into the other stage before the MFMAs
+      const bool nxt = advance();
+      if (nxt) {
+        issue(st ^ 1);
+        rem = klen - kk;
+      }
+      mfma_step(st);
+      if (!nxt) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                          // step k+1 has landed; everybody has left stage st
+      if (rem < BK) { clear_tail(st ^ 1, rem); __syncthreads(); }
+      st ^= 1;
+    }
+  }
+
+  // ---- epilogue --------------------------------------------------------------
+  const int lr = lane >> 4, lc = lane & 15;
+  if (u.mode == MODE_SCATTER) {
+    // fused expand_buffer: dest[(relpos[i]-r0)*ld + (gcol[j]-c0)] -= acc
+    double* D = L + u.d_off;
+    int dcol[FMN];
+#pragma unroll
+    for (int b = 0; b < FMN; ++b) {
+      const int j = j0 + wn * (T / WN) + b * 16 + lc;
+      dcol[b] = (j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
+    }
+#pragma unroll
+    for (int a = 0; a < FMM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
+        if (i >= M) continue;
+        const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
+            unsafeAtomicAdd(D + drow + dcol[b], -acc[a][b][r]);
+        }
+      }
+  } else {
+    double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
+    // TRSM writes X in place, BUFFER stores the product into the scratch block: plain stores
+    const bool trsm = (u.mode == MODE_TRSM) || (u.mode == MODE_BUFFER);
+    const bool atomic = u.atomic != 0;
+#pragma unroll
+    for (int a = 0; a < FMM; ++a) {
+      // The tile owns its destination entries unless the unit says otherwise, so
+      // the update is a plain read-modify-write; the 4 * FMN loads of a fragment
+      // row are issued together (loads interleaved with the stores would
+      // serialise into one global round trip each).  Atomics cost more: the chip
+      // adds ~1.3 TB/s of atomic bytes, a third of what plain traffic gets.
+      bool ok[4][FMN];
+      double cv[4][FMN];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
+        const double* drow = D + (int64_t)min(i, M - 1) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          ok[r][b] = i < M && j < N && (trsm || !u.lower || u.src_r0 + i >= u.src_c0 + j);
+          cv[r][b] = (ok[r][b] && !trsm && !atomic) ? drow[j] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
+        double* drow = D + (int64_t)min(i, M - 1) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          if (!ok[r][b]) continue;
+          if (trsm) drow[j] = acc[a][b][r];
+          else if (atomic) unsafeAtomicAdd(drow + j, -acc[a][b][r]);
+          else drow[j] = cv[r][b] - acc[a][b][r];
+        }
+      }
+    }
+  }
+}
+
+
+// the two instantiations, with the register budget (second launch bound = waves per SIMD) that
+// keeps 2 (128-tile) / 5 (64-tile) workgroups per CU resident
+__global__ __launch_bounds__(512, 4) void k_update_dma128(
+    const UpdTile* __restrict__ tiles, const UpdUnit* __restrict__ units, const int64_t* __restrict__ bc_off,
+    const int* __restrict__ bc_w, double* __restrict__ L, const int* __restrict__ relpos,
+    const int* __restrict__ rlist, const double* __restrict__ dinv, int prio) {
+  update_dma_body<128, 4, 2>(tiles, units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+}
+__global__ __launch_bounds__(256, 5) void k_update_dma64(
+    const UpdTile* __restrict__ tiles, const UpdUnit* __restrict__ units, const int64_t* __restrict__ bc_off,
+    const int* __restrict__ bc_w, double* __restrict__ L, const int* __restrict__ relpos,
+    const int* __restrict__ rlist, const double* __restrict__ dinv, int prio) {
+  update_dma_body<64, 2, 2>(tiles, units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+}
+
 // ---------------------------------------------------------------------------
 // a26: extend-add of a generated element window into an ancestor tile,
 // dest[pos_r(i)][pos_c(j)] -= src[i][j]; positions found by binary search in
@@ -1367,7 +1617,7 @@ void launch_poison_lds(hipStream_t st) {
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv, int prio,
-                   int lds_pad) {
+                   int lds_pad, bool allow_dma) {
   if (count <= 0) return;
   // lds_pad: extra (unused) dynamic LDS that caps the workgroups per CU of a
   // trailing-update launch so that panel-chain kernels find room beside it
@@ -1391,6 +1641,33 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_dev = dev;
     }
+  }
+  // operand tiles straight into LDS (k_update_dma) for the 128- and 64-tiles; SPLLT_UPD_DMA=0: the
+  // register-staged kernels
+  static const bool use_dma = [] {
+    const char* e = std::getenv("SPLLT_UPD_DMA");
+    return !(e && std::atoi(e) == 0);
+  }();
+  // (the 64-tile loses with it: 96 registers for 5 waves per SIMD cost spills, 47.3 vs 51.8 TFLOP/s at K = 256;
+  // SPLLT_UPD_DMA=2 selects it all the same)
+  static const bool dma64 = [] { const char* e = std::getenv("SPLLT_UPD_DMA"); return e && std::atoi(e) == 2; }();
+  if (use_dma && allow_dma && (tile == 128 || (tile == 64 && dma64))) {
+    const unsigned lds = (unsigned)(2 * 2 * tile * 128) + (lds_pad > 0 ? (unsigned)lds_pad : 0u);
+    thread_local int attr_dev2 = -1;
+    int dev2 = 0;
+    (void)hipGetDevice(&dev2);
+    if (dev2 != attr_dev2) {
+      (void)hipFuncSetAttribute((const void*)k_update_dma128, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_update_dma64, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_dev2 = dev2;
+    }
+    if (tile == 128)
+      hipLaunchKernelGGL(k_update_dma128, dim3((unsigned)count), dim3(512), lds, st, tiles, units, bc_off,
+                         bc_w, L, relpos, rlist, dinv, prio);
+    else
+      hipLaunchKernelGGL(k_update_dma64, dim3((unsigned)count), dim3(256), lds, st, tiles, units, bc_off,
+                         bc_w, L, relpos, rlist, dinv, prio);
+    return;
   }
   if (tile == 128)
     hipLaunchKernelGGL((k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>), dim3((unsigned)count),

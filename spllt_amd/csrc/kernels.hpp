@@ -31,7 +31,9 @@ void launch_poison_lds(hipStream_t st);
 void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv, int prio = 0,
-                   int lds_pad = 0);
+                   int lds_pad = 0, bool allow_dma = true);
+// (allow_dma = false: the register-staged kernels -- for operands in caller-owned buffers without
+// slack behind them: the DMA kernels load whole 16-column chunks)
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,
                           const int* csrc_index, const double* src, int lds,
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,

@@ -67,7 +67,7 @@ struct OpsBatch {
       std::vector<int> zeros(2 * std::max<size_t>(1, P.panel_units.size()), 0);
       up((void**)&d_pcnt, zeros.data(), zeros.size() * sizeof(int));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * std::max<int64_t>(1, P.dinv_size));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * (std::max<int64_t>(1, P.dinv_size) + 32));
     if (e == hipSuccess && !d_flag) {
       own_flag = true;
       int big = INT_MAX;
@@ -86,7 +86,7 @@ struct OpsBatch {
           launch_panel(st, d_tiles + l.first, l.count, d_panel, base, d_dinv, d_pcnt, d_flag);
         else
           launch_update(st, l.tile, d_tiles + l.first, l.count, d_units, d_off, d_w, base, relpos,
-                        rlist, d_dinv);
+                        rlist, d_dinv, 0, 0, false);   // (caller-owned tiles: no slack for whole-chunk loads)
       }
       e = hipGetLastError();
       hipError_t e2 = hipStreamSynchronize(st);
