@@ -68,7 +68,9 @@ def build_workload(args):
     return A, n, ptr, row, val, order, nb, name, cfg
 
 
-UPDATE_KERNELS = {128: "k_update<128, 16, 4, 2>", 64: "k_update<64, 16, 2, 2>", 32: "k_update<32, 32, 2, 2>"}
+# (the 128-tile is the LDS-DMA kernel unless SPLLT_UPD_DMA=0 selects the register-staged one)
+UPDATE_KERNELS = {128: "k_update<128, 16, 4, 2>" if os.environ.get("SPLLT_UPD_DMA") == "0" else "k_update_dma128",
+                  64: "k_update<64, 16, 2, 2>", 32: "k_update<32, 32, 2, 2>"}
 
 
 def roofline_from_profile(f, val):

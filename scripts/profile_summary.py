@@ -164,7 +164,8 @@ def main():
                        "per MI355X_MICROARCH.md, upper bound for these 8-B/lane loads); scatter_atomic_GBps = 8 B x "
                        "destination entries / time of the inter-node update launches (chip limit ~1300 GB/s)"}
     # kernel names as bench.py spells them
-    summary["kernels"] = {("k_update<" + k.split("k_update<")[1].split(">")[0] + ">") if "k_update<" in k else k: v
+    summary["kernels"] = {("k_update<" + k.split("k_update<")[1].split(">")[0] + ">") if "k_update<" in k else
+                          ("k_update_dma128" if "k_update_dma128" in k else k): v
                           for k, v in summary["kernels"].items()}
     with open(os.path.join(d, "summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
