@@ -734,3 +734,30 @@ def test_bench_contract_one_gpu():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     chk = d["detail"]["check"]
     assert chk["bwd_err"] <= 1e-14 and chk["max_relerr_L_vs_cpu"] <= 1e-12
+
+
+@pytest.mark.parametrize("flags", [0, 2, 4096])
+@pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.fe27((14, 13, 12), 3), 200, None),     # K windows of 200 = 12 x 16 + 8
+                                       (lambda: matgen.nd_like((16, 15, 14), 3), 150, 48),    # 150 = 9 x 16 + 6, panels of 48
+                                       (lambda: matgen.poisson3d(30), 37 * 8, None),           # nb = 296
+                                       (lambda: matgen.nd_like((13, 12, 11), 3), 111, 37)])    # odd widths: rows 8-byte aligned only
+def test_dma_update_kernel_on_every_large_launch(gen, nb, pw, flags, monkeypatch):
+    """k_update_dma128 (operand tiles DMA'd straight into swizzled LDS stages): by default only
+    launches of >= 4096 tiles use the 128-tile; here every update with M, N >= 96 does, on shapes
+    whose K windows are no multiple of the 16-column chunks (whole chunks are loaded, the excess is
+    cleared in LDS) and whose rows are only 8-byte aligned, in the default, single-stream and
+    deterministic (BUFFER epilogue) engines."""
+    monkeypatch.setenv("SPLLT_TILE_SMALL", "0")
+    monkeypatch.setenv("SPLLT_TILE_TINY", "0")
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=16, panel_width=pw, engine_flags=flags)
+    L = f.program("launches")
+    assert ((L[:, 0] == 1) & (L[:, 4] == 128) & (L[:, 3] > 0)).sum() >= 5, "expected 128-tile launches"
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val, variant="mkl", nthreads=8)
+    assert rc == 0
+    mask = lower_mask(f)
+    assert rel_err(got, o.arena(), mask) <= TOL_L
+    assert np.all(got[~mask] == 0.0)
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
