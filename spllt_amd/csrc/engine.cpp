@@ -170,6 +170,9 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     if (opt_.reserve_cus < 0) opt_.reserve_cus = lb ? 32 : 0;
     if (opt_.zones < 0) opt_.zones = lb ? 1 : 0;
     so.zones = opt_.zones != 0;
+    // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
+    // large configurations; the latency-bound bench workload prefers 4096 (24.5 vs 25.0 ms)
+    so.tile128_min = lb ? 4096 : 1024;
   }
   if (opt_.nranks > 1) {
     partition_options(*S_, opt_, owner_, top_owner_, so);

@@ -78,7 +78,7 @@ struct Builder {
       if (pick_tile(u.M, u.N) == 128) n128 += (int64_t)cdiv(u.M, 128) * cdiv(u.N, 128);
       n64 += (int64_t)cdiv(u.M, 64) * cdiv(u.N, 64);
     }
-    const int64_t small_max = env_int("SPLLT_TILE_SMALL", 4096);
+    const int64_t small_max = env_int("SPLLT_TILE_SMALL", opt.tile128_min);
     const int64_t tiny_max = env_int("SPLLT_TILE_TINY", 2048);
     const bool small_launch = n128 > 0 && n128 < small_max;
     // 32-tiles are for latency: throughput launches (bulk / far streams: trailing updates,

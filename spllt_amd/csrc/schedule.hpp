@@ -245,6 +245,8 @@ struct ScheduleOptions {
                               // CUs are free, and a launch that needs a second round of them loses
                               // what the two saved kernel boundaries gain: 26.3 ms unfused, 25.9 with
                               // 64, 26.3 with 128, 28.4 with 512 on the nd24k stand-in)
+  int tile128_min = 4096;     // launches of up to this many 64-tiles keep 64-tiles (the 128-tile pays when a
+                              // launch fills the chip for several rounds; throughput-bound problems: 1024)
   bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
