@@ -12,6 +12,8 @@
 //                   (:2108-2237, :2010-2053) with the scatter fused into the GEMM
 //                   epilogue, or (deterministic engine) stored into a scratch block
 //                   -- one fp64-MFMA kernel, four epilogues.
+//   k_update_dma128 the 128-tile of the same product with the operand tiles DMA'd straight into
+//                   two XOR-swizzled LDS stages (global_load_lds_dwordx4)
 //   k_gather        a18 turned destination-centric: ordered assembly of the buffered update
 //                   blocks (deterministic engine, no atomics)
 //   k_scatter_block a26 spllt_scatter_block (:1122-1160) extend-add
