@@ -238,3 +238,65 @@ def test_bench_contract_two_ranks_over_gloo(dist_top):
     assert d["value"] > 0 and d["detail"]["partition_width"] == 2
     assert d["detail"]["distributed_top_tree"] == (dist_top == "1")
     assert d["detail"]["check"]["bwd_err"] <= 1e-14
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_top_tree_block_column_owners(world):
+    """Distributed top tree: every block column of the top tree has exactly one owner, the owners
+    are dealt round-robin in the order the top tree is walked (level, block-column step, node) --
+    so the block columns of one step sit on different ranks as far as there are ranks -- and
+    nothing outside the top tree has one.  The exchanges of every rank's program are the same list."""
+    from helpers import make_case
+    from spllt_amd import matgen
+    A = matgen.nd_like((14, 13, 12), 2)
+    fs = []
+    for r in range(world):
+        f, _ = make_case(A, nb=32, nemin=8, prune=True, ncpu=world, engine_flags=8192)
+        f.set_partition(r, world)
+        fs.append(f)
+    f = fs[0]
+    owner, towner = f.partition("owner"), f.partition("top_bcol_owner")
+    bc_node, level, nb0 = f.sym("bcol_node"), f.sym("level"), f.sym("node_bcol0")
+    top = np.nonzero(owner[bc_node] < 0)[0]
+    assert len(towner) == len(bc_node)
+    assert np.all(towner[top] >= 0) and np.all(towner[top] < world)
+    assert np.all(np.delete(towner, top) == -1)
+    # walk order: level, step c, node
+    order = sorted(top.tolist(), key=lambda b: (level[bc_node[b]], b - nb0[bc_node[b]], bc_node[b]))
+    assert [int(towner[b]) for b in order] == [i % world for i in range(len(order))]
+    if len(top) >= world:
+        assert set(towner[top].tolist()) == set(range(world))
+    ex0, it0 = f.program("exchanges"), f.program("xitems")
+    assert ex0[0, 0] == 1 and ex0[-1, 0] == 3 and np.all(ex0[1:-1, 0] == 2)
+    for g in fs[1:]:
+        assert np.array_equal(g.program("exchanges"), ex0) and np.array_equal(g.program("xitems"), it0)
+        assert np.array_equal(g.partition("top_bcol_owner"), towner)
+    # a broadcast item's root is the owner; the reduce-scatter chunks are disjoint and in rank order
+    for kind, first, n, elems, chunk in ex0.tolist():
+        items = it0[first:first + n]
+        if kind == 2:
+            assert all(int(towner[b]) == root for b, root in items[:, :2].tolist())
+        if kind == 1:
+            assert elems == chunk * world
+            for b, root, xo, cnt, off, space in items.tolist():
+                assert root * chunk <= xo and xo + cnt <= (root + 1) * chunk and space == 0
+
+
+def test_top_tree_is_distributed_only_when_it_pays():
+    """The engine's choice (distribute_top_tree): a top tree that is a chain of dependent panel
+    steps (small problem) stays replicated -- distributing it would only add a broadcast per
+    step --, a compute-bound one is distributed; flags 8192 / 16384 force either."""
+    from helpers import make_case
+    from spllt_amd import matgen
+    small = matgen.nd_like((10, 9, 8), 2)
+    f, _ = make_case(small, nb=32, nemin=8, prune=True, ncpu=4)
+    f.set_partition(0, 4)
+    assert len(f.partition("top_bcol_owner")) == 0            # replicated by choice
+    for flag, want in ((8192, True), (16384, False)):
+        g, _ = make_case(small, nb=32, nemin=8, prune=True, ncpu=4, engine_flags=flag)
+        g.set_partition(0, 4)
+        assert (len(g.partition("top_bcol_owner")) > 0) == want
+    big = matgen.poisson3d(112)                                # 5.5 TFLOP, most of it in the top of the tree
+    h, _ = make_case(big, nb=384, nemin=32, prune=True, ncpu=4)
+    h.set_partition(0, 4)
+    assert len(h.partition("top_bcol_owner")) > 0              # distributed by choice
