@@ -114,7 +114,7 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * bit 7 = debug: the LDS of every CU is filled with signalling NaNs before every
  * kernel launch (a kernel that reads LDS it has not written then computes NaNs),
  * bit 8 = no CU reservation (default: the streams that carry the trailing updates
- * are masked off 16 CUs, which the latency-critical panel-chain kernels then find
+ * are masked off the last 32 CUs (latency-bound problems only), which the latency-critical panel-chain kernels then find
  * free).  Bit 9 = no fused panel launches: by default a panel step whose block columns have
  * few rows below the panel (at most 64 blocks of 64 rows in the launch) runs as ONE kernel -
  * every workgroup factors the 64 x 64 diagonal block itself, solves its own rows and applies
