@@ -328,6 +328,9 @@ int Engine::upload() {
   HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)(std::max<int64_t>(1, arena_elems_) + 32)), "hipMalloc(L arena)");
   HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
   HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMalloc(dinv)");
+  // the POTRF kernels store the lower triangle of an inverted panel only; what lies above the
+  // diagonal of a slot is zero from here on (nothing else writes there)
+  HIPCHK(hipMemset(d_dinv_, 0, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMemset(dinv)");
   if (opt_.nranks > 1) {
     // this rank scatters A only into its own subtrees; the top tree's values
     // are contributed by rank 0 alone so that the cross-rank sum holds them once
@@ -457,7 +460,7 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
   if (l.count > 0 && l.kind != L_EXCHANGE) {
     if (opt_.poison_lds) launch_poison_lds(st);
     if (l.kind == L_CHAIN) {
-      launch_chain_panel(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_);
+      launch_chain_panel(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
     } else if (l.kind == L_PANEL) {
       launch_panel(st, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
     } else if (l.kind == L_GATHER) {

@@ -31,6 +31,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -155,8 +156,10 @@ __device__ inline void rsqrt_sqrt(double d, double& y, double& r) {
 #ifdef POTRF_STAMPS
 __device__ unsigned long long g_potrf_stamps[32];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP2(c, i) do { if ((c) && blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP2(c, i) do { } while (0)
 #endif
 
 struct PotrfShared {
@@ -371,14 +374,368 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
   (void)np;
 }
 
+// ---------------------------------------------------------------------------
+// The default POTRF body (round 3).  Same result as potrf64_body (L_pp in place, inv(L_pp) to
+// D), organised around ONE critical path -- the four 16 x 16 register Choleskys of wave 0 --
+// with everything else moved into its shadow:
+//   * the 16 x 16 factorization runs in LDL^T order: the serial chain per pivot is
+//     d_j -> 1/d_j (v_rcp_f64 + two Newton steps) -> multiplier -> next diagonal entry, about
+//     a third of the reciprocal-square-root chain; the square roots are taken once, for all 16
+//     pivots at the same time (lane j: d_j), after the loop.  The broadcasts of the pivot column
+//     cost nothing: v_fmac_f64_dpp row_newbcast reads lane k of the row of 16 lanes as an
+//     operand (round 2: two v_mov_b32_dpp per FMA; 415 cycles per pivot, now ~110).
+//   * right-looking: after the solve of the blocks below (A3) wave 0 only updates the NEXT
+//     diagonal block and goes on; waves 1-3 meanwhile apply the finished block column to the
+//     other trailing blocks, compute the finished block ROW of the inverse
+//     (X_JK = -W_JJ sum_M L_JM X_MK: needs rows < J of X only) and send the finished rows of L
+//     and X home (a CU stores ~10 B/cycle: 64 KB at the end of the kernel were 4-7 k cycles).
+// flags: bit 1 the caller stores L itself; bit 2 neither the inverse is stored nor a failed pivot
+// reported; bit 3 the upper triangle of the inverse's slot is already zero and stays so (the
+// engine clears the dinv scratch once): only the lower triangle is stored.
+// ---------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// The register Cholesky below is a fixed sequence of volatile inline-assembly instructions (the
+// compiler only allocates the registers): left to itself the compiler puts the whole reciprocal
+// chain of pivot j+1 BEHIND the ~30 update FMAs of pivot j instead of into their issue slots, and
+// sched_barrier does not bind inline assembly.  The hazards the compiler would pad are padded by
+// hand and checked at build time (scripts/check_dpp_hazards.py):
+//   * a VGPR written by a vector instruction must not be read by a DPP instruction in the next
+//     two issue slots (s_nop 1 behind the pivot column's update, whose result is broadcast next);
+//   * the result of v_rcp_f64 must not be consumed by the very next instruction (s_nop 0).
+// acc += (lane K of this row of 16 lanes: s0) * s1, one VOP2-DPP instruction
+template <int K>
+__device__ __forceinline__ void fmac_bc(double& acc, double s0, double s1) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s0), "v"(s1), "n"(K));
+}
+// the same for the next pivot's column, followed by the broadcast of the new pivot d = acc[lane K]
+template <int K>
+__device__ __forceinline__ void fmac_bc_pivot(double& acc, double s0, double s1, double& d) {
+  asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_mov_b64_dpp %1, %0 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc), "=&v"(d) : "v"(s0), "v"(s1), "n"(K));
+}
+__device__ __forceinline__ double rcp_newton(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
+}
+__device__ __forceinline__ double a_rcp(double d) {
+  double y;
+  asm volatile("v_rcp_f64 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(d));
+  return y;
+}
+__device__ __forceinline__ double a_nr_err(double d, double y) {      // 1 - d y
+  double e;
+  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(d), "v"(y));
+  return e;
+}
+__device__ __forceinline__ void a_nr_fix(double& y, double e) {        // y += y e
+  asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(y) : "v"(e));
+}
+__device__ __forceinline__ double a_nmul(double a, double b) {         // -(a b)
+  double o;
+  asm volatile("v_mul_f64 %0, %1, -%2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+__device__ __forceinline__ double a_mul(double a, double b) {
+  double o;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+__device__ __forceinline__ double a_sub(double a, double b) {
+  double o;
+  asm volatile("v_add_f64 %0, %1, -%2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+// 16 x 16 Cholesky + inverse in registers.  Lane i of every row of 16 lanes holds row i of the
+// block (row[c]; four identical copies per wave); on return row[c] = L[i][c] for c <= i
+// (garbage above the diagonal) and wx[c] = W[c][i], column i of W = inv(L).  Returns the first
+// failed pivot (1 << 30: none); a failed pivot is not repaired (the block fills with NaNs or
+// garbage and the factorization is reported as failed).
+__device__ __forceinline__ int chol16_regs(double (&row)[16], double (&wx)[16], int lr) {
+  double wacc[16], delta[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    wacc[c] = 0.0;
+    delta[c] = (lr == c) ? 1.0 : 0.0;
+  }
+  double dn = bcast_row<0>(row[0]);
+  double dmine = dn;
+  double y = rcp_newton(dn);
+  STAMP2(true, 21);
+  static_for<0, 16>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    using std::integral_constant;
+    // row i, column j holds m_ij = l_ij d_j (unscaled); multiplier l_ij = m_ij / d_j = m_ij y
+    const double nsc = a_nmul(row[j], y);
+    if constexpr (j + 1 < 16) {
+      // the updates of pivot j -- a_ik -= l_ij m_kj (k = j+2..15), then the inverse of the unit
+      // lower factor that rides along, wacc[k] += l_kj Wu[j][c] (k = j+1..15) -- are dealt into
+      // the latency gaps of pivot j+1's reciprocal chain
+      constexpr int nR = 14 - j, nF = 29 - 2 * j;
+      double wxj = 0.0, z = 0.0;
+      auto fill = [&](auto lo, auto hi) {
+        static_for<decltype(lo)::value, decltype(hi)::value>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (i < nR) {
+            fmac_bc<j + 2 + i>(row[j + 2 + i], row[j], nsc);
+          } else {
+            if constexpr (i == nR) {
+              // Wu[j][c] = delta_jc - sum_{k<j} l_jk Wu[k][c]
+              wxj = a_sub(delta[j], wacc[j]);
+              z = a_mul(wxj, y);
+            }
+            fmac_bc<j + 1 + i - nR>(wacc[j + 1 + i - nR], row[j], z);
+          }
+        });
+      };
+      constexpr int b0 = nF * 30 / 100, b1 = nF * 44 / 100, b2 = nF * 58 / 100, b3 = nF * 72 / 100;
+      fmac_bc_pivot<j + 1>(row[j + 1], row[j], nsc, dn);   // the next pivot's column first
+      double yn = a_rcp(dn);
+      fill(integral_constant<int, 0>{}, integral_constant<int, b0>{});
+      double e = a_nr_err(dn, yn);
+      fill(integral_constant<int, b0>{}, integral_constant<int, b1>{});
+      a_nr_fix(yn, e);
+      fill(integral_constant<int, b1>{}, integral_constant<int, b2>{});
+      e = a_nr_err(dn, yn);
+      fill(integral_constant<int, b2>{}, integral_constant<int, b3>{});
+      a_nr_fix(yn, e);
+      fill(integral_constant<int, b3>{}, integral_constant<int, nF>{});
+      dmine = (lr == j + 1) ? dn : dmine;
+      wx[j] = wxj;
+      y = yn;
+    } else {
+      wx[j] = delta[j] - wacc[j];
+    }
+  });
+  STAMP2(true, 22);
+  // L = M diag(d)^-1/2, W = diag(d)^-1/2 Wu: all 16 square roots at once (lane j: d_j)
+  double ys, rs;
+  rsqrt_sqrt(dmine, ys, rs);
+  // (the diagonal comes out as d_j / sqrt(d_j): within an ulp or two of sqrt(d_j); the pins
+  // keep the products here: the callers store row[] and wx[] in different branches, into which
+  // the compiler would otherwise sink them one by one)
+  static_for<0, 16>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double sc = bcast_row<c>(ys);
+    row[c] *= sc;
+    wx[c] *= sc;
+    asm volatile("" : "+v"(row[c]), "+v"(wx[c]));
+  });
+  (void)rs;
+  STAMP2(true, 23);
+  // lane j holds pivot j: the first one that is not positive
+  const unsigned long long bad = __ballot(!(dmine > 0.0)) & 0xffffull;
+  return bad ? __builtin_ctzll(bad) : (1 << 30);
+}
+
+__device__ __forceinline__ void potrf64_v2(PotrfShared& sh, double* __restrict__ A, int ld, int n,
+                                           double* __restrict__ D, int ldd, int gcol, int flags,
+                                           int* __restrict__ flag) {
+  double (&T)[64 * TLD] = sh.T;
+  double (&X)[64 * TLD] = sh.X;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int nblk = (n + 15) >> 4;
+  const bool st_l = !(flags & 2), st_i = !(flags & 4), x_lower = (flags & 8) != 0;
+  STAMP(0);
+  // identity-padded lower triangle into LDS (see potrf64_body)
+  const int lw = tid >> 6, lc = tid & 63;
+  if (tid < 256) {
+    // (unconditional loads at clamped addresses; the columns right of the row's diagonal block
+    // re-read its last column, which costs no traffic)
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + lw;
+      const int cmax = min(n - 1, r | 15);
+      v[e] = A[(int64_t)(r < n ? r : n - 1) * ld + (lc < cmax ? lc : cmax)];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[(4 * e + lw) * TLD + lc] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + lw;
+      T[r * TLD + lc] = (r < n && lc <= r) ? v[e] : ((r == lc) ? 1.0 : 0.0);
+    }
+  }
+  __syncthreads();
+  STAMP(1);
+  // rows [row0, row0 + 8) x columns [col0, col0 + 16) of the LDS image M (row stride TLD) -> dst
+  // (row stride ldst), entries on or below the diagonal only: ONE wave-instruction, 8 lanes per
+  // row, two columns (16 bytes) per lane -- a CU retires stores by the instruction, and one row of
+  // 8-byte lanes per instruction made the stores the longest part of the kernel
+  auto store_rows8 = [&](double* __restrict__ dst, int ldst, const double* M, int row0, int col0) {
+    const int g = row0 + (lane >> 3), c = col0 + 2 * (lane & 7);
+    const int cend = min(g, n - 1);                 // last column to store
+    if (g >= n || c > cend) return;
+    const double v0 = M[g * TLD + c], v1 = M[g * TLD + c + 1];
+    double* q = dst + (int64_t)g * ldst + c;
+    if (c + 1 <= cend) {
+      typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+      *reinterpret_cast<d2*>(q) = (d2){v0, v1};
+    } else {
+      q[0] = v0;
+    }
+  };
+  // block (I, Jp) -= T[I][S] T[Jp][S]^T
+  auto upd_block = [&](int I, int Jp, int S) {
+    d4 acc = ld_c(T, I * 16, Jp * 16, lane);
+    double a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = -T[(I * 16 + lr) * TLD + S * 16 + 4 * t + lq];
+      b[t] = T[(Jp * 16 + lr) * TLD + S * 16 + 4 * t + lq];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+    st_c(T, I * 16, Jp * 16, lane, acc);
+  };
+  // The work in the shadow of wave 0, shared by ns waves (this one: ws); step S is final: block
+  // column S of L and W_SS.  Wave ws owns block column K = ws of the inverse: Xpre carries
+  // sum_{M=K}^{S-1} L_SM X_MK from the previous shadow (it needs nothing of step S), so that
+  // X_SK = -W_SS Xpre is four MFMAs once W_SS exists -- which matters for the LAST block row,
+  // the only one that is not hidden behind a register Cholesky.
+  d4 Xpre = {0.0, 0.0, 0.0, 0.0};
+  auto shadow = [&](int S, int ws, int ns, bool stores) {
+    const int K = ws;
+    if (K < S) {
+      d4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const double a = -X[(S * 16 + lr) * TLD + S * 16 + 4 * tt + lq];     // W_SS[lr][k]
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xpre[tt], R, 0, 0, 0);
+      }
+      st_c(X, S * 16, K * 16, lane, R);
+      if (st_i && x_lower) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int g = S * 16 + lq + 4 * r;
+          if (g < n) D[(int64_t)g * ldd + K * 16 + lr] = R[r];
+        }
+      }
+    }
+    int t = 0;
+    for (int Jp = S + 1; Jp < nblk; ++Jp)
+      for (int I = Jp; I < nblk; ++I) {
+        if (I == S + 1 && Jp == S + 1) continue;         // wave 0's
+        if (t++ % ns == ws) upd_block(I, Jp, S);
+      }
+    if (S + 1 < nblk && K <= S) {
+      // for the next block row: sum_{M=K}^{S} L_{S+1,M} X_MK  (X_SK: just written by this wave, or W_SS)
+      Xpre = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int M = K; M <= S; ++M) {
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const double a = T[((S + 1) * 16 + lr) * TLD + M * 16 + k + lq];
+          const double b = X[(M * 16 + k + lq) * TLD + K * 16 + lr];
+          Xpre = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Xpre, 0, 0, 0);
+        }
+      }
+    }
+    // block column S of L (final with step S) and the diagonal block of the inverse go home
+    if (!stores) return;
+    const int ngrp = (64 - S * 16) / 8;
+    for (int gi = ws; gi < ngrp; gi += ns)
+      if (st_l) store_rows8(A, ld, T, S * 16 + gi * 8, S * 16);
+    if (st_i && x_lower)
+      for (int gi = ws; gi < 2; gi += ns) store_rows8(D, ldd, X, S * 16 + gi * 8, S * 16);
+  };
+  for (int J = 0; J < nblk; ++J) {
+    if (w == 0) {
+      if (J > 0) upd_block(J, J, J - 1);                  // the only update on the critical path
+      double row[16], wx[16];
+      STAMP2(true, 20);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = T[(J * 16 + lr) * TLD + J * 16 + c];
+      const int failcol = chol16_regs(row, wx, lr);
+      STAMP2(true, 24);
+      // the four rows of 16 lanes hold identical copies: row 0 writes L_JJ (the entries above
+      // the diagonal are never read by anybody: left as they are), row 1 W_JJ into the inverse
+      // (where the solve of the blocks below and the recurrences of the inverse read it)
+      if (lq == 0) {
+        double* dst = &T[(J * 16 + lr) * TLD + J * 16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c] = row[c];
+        if (failcol != (1 << 30) && lane == 0 && st_i) atomicMin(flag, gcol + J * 16 + failcol + 1);
+      } else if (lq == 1) {
+        double* dst = &X[(J * 16) * TLD + J * 16 + lr];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dst[c * TLD] = wx[c];
+      }
+      STAMP2(true, 25);
+    } else if (w < 4 && J > 0) {
+      shadow(J - 1, w - 1, 3, true);
+    }
+    __syncthreads();
+    STAMP(2 + 2 * J);
+    // blocks below: X_IJ = A_IJ inv(D_J)^T
+    if (w < 4 && J + 1 + w < nblk) {
+      const int I = J + 1 + w;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double a = T[(I * 16 + lr) * TLD + J * 16 + 4 * t + lq];
+        const double b = X[(J * 16 + lr) * TLD + J * 16 + 4 * t + lq];     // W_JJ[lr][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      st_c(T, I * 16, J * 16, lane, acc);
+    }
+    __syncthreads();
+    STAMP(3 + 2 * J);
+  }
+  // the last step's shadow: the last block row of the inverse, the last diagonal blocks (wave 0
+  // takes the stores of its own blocks, waves 1-3 finish their block of the inverse)
+  if (w > 0 && w < 4) {
+    const int S = nblk - 1, K = w - 1;
+    if (K < S) shadow(S, K, 3, false);                    // (no updates are left; wave 0 stores)
+  } else if (w == 0) {
+    const int S = nblk - 1;
+    if (st_l) { store_rows8(A, ld, T, S * 16, S * 16); store_rows8(A, ld, T, S * 16 + 8, S * 16); }
+    if (st_i && x_lower) { store_rows8(D, ldd, X, S * 16, S * 16); store_rows8(D, ldd, X, S * 16 + 8, S * 16); }
+  }
+  STAMP(10);
+  if (st_i && !x_lower) {
+    // a caller-owned slot that is not known to be zero above the diagonal (operator twins): whole rows
+    __syncthreads();
+    if (tid < 256)
+      for (int r = lw; r < n; r += 4)
+        if (lc < n) D[(int64_t)r * ldd + lc] = X[r * TLD + lc];
+  }
+  STAMP(11);
+}
+
+// factorizations take the round-3 body, "invert only" (flags bit 0: operator twins) the older one
+__device__ __forceinline__ void potrf64(PotrfShared& sh, double* __restrict__ A, int ld, int n,
+                                        double* __restrict__ D, int ldd, int gcol, int flags,
+                                        int* __restrict__ flag) {
+#ifndef POTRF_V1
+  if (!(flags & 1)) {
+    potrf64_v2(sh, A, ld, n, D, ldd, gcol, flags, flag);
+    return;
+  }
+#endif
+  potrf64_body(sh, A, ld, n, D, ldd, gcol, flags, flag);
+}
+
+// (u0 = units[0] by value: the descriptor of workgroup 0 -- on the critical path of the top
+// levels a launch has ONE workgroup -- arrives with the kernel arguments instead of through a
+// dependent global load in front of the block's loads)
 __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict__ units,
                                                      double* __restrict__ L,
                                                      double* __restrict__ dinv,
-                                                     int* __restrict__ flag) {
+                                                     int* __restrict__ flag, const PotrfUnit u0) {
   __shared__ PotrfShared sh;
   __builtin_amdgcn_s_setprio(3);
-  const PotrfUnit u = units[blockIdx.x];
-  potrf64_body(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.n, u.gcol, u.flags, flag);
+  const PotrfUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
+  potrf64(sh, L + u.off, u.ld, u.n, dinv + u.dinv_off, u.n, u.gcol, u.flags, flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -397,13 +754,15 @@ __global__ __launch_bounds__(256) void k_potrf_panel(const PotrfUnit* __restrict
 __global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict__ units,
                                                      double* __restrict__ L,
                                                      double* __restrict__ dinv,
-                                                     int* __restrict__ flag) {
+                                                     int* __restrict__ flag, const ChainUnit u0) {
   __shared__ PotrfShared sh;
   __builtin_amdgcn_s_setprio(3);
-  const ChainUnit u = units[blockIdx.x];
+  const ChainUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
   const int cq = u.c0 - u.cs;
-  potrf64_body(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, cq + u.pn,
-               u.gcol, 0, flag);
+  // (flags 8: the dinv scratch is cleared when it is allocated, and nothing ever writes above the
+  // diagonal of a slot)
+  potrf64(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, cq + u.pn,
+          u.gcol, 8, flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -497,7 +856,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
   // ---- 1. the panel's diagonal block (the first workgroup stores the inverse and reports a
   // failed pivot; L_pp goes home from the workgroup that read the block last) ---------------
   double* Dg = A + (int64_t)c0 * ld + c0;
-  potrf64_body(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? 2 : 6, flag);
+  potrf64(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? (2 | 8) : 6, flag);
   __syncthreads();
   if (last_reader(counters + 2 * tl.unit, u.ntile, &vote)) {
     const int lc = tid & 63;       // a wave-instruction writes (part of) one row
@@ -1505,15 +1864,15 @@ void launch_scatter_val(hipStream_t st, double* L, const double* val, const int6
 }
 
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
-                  int* flag) {
+                  int* flag, const PotrfUnit& unit0) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+  hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag, unit0);
 }
 
 void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
-                        int* flag) {
+                        int* flag, const ChainUnit& unit0) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag);
+  hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag, unit0);
 }
 
 void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,

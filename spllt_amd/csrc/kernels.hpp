@@ -11,11 +11,12 @@ namespace spx {
 
 void launch_scatter_val(hipStream_t st, double* L, const double* val, const int64_t* dst,
                         const int64_t* src, int64_t n);
+// (unit0 = host copy of units[0]: travels with the kernel arguments)
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
-                  int* flag);
+                  int* flag, const PotrfUnit& unit0);
 // one step of the panel chain per workgroup (ChainUnit): POTRF of the panel + its inverse
 void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
-                        int* flag);
+                        int* flag, const ChainUnit& unit0);
 // one whole panel step per launch (PanelUnit; tiles: unit, ti = 64-row block below the panel)
 // counters: two zero-initialised ints per panel unit (left zero again by the launch)
 void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,

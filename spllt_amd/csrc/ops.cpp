@@ -68,6 +68,8 @@ struct OpsBatch {
       up((void**)&d_pcnt, zeros.data(), zeros.size() * sizeof(int));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&d_dinv, sizeof(double) * (std::max<int64_t>(1, P.dinv_size) + 32));
+    // (the POTRF kernels store the lower triangle of an inverse only: the rest of a slot stays zero)
+    if (e == hipSuccess) e = hipMemset(d_dinv, 0, sizeof(double) * (std::max<int64_t>(1, P.dinv_size) + 32));
     if (e == hipSuccess && !d_flag) {
       own_flag = true;
       int big = INT_MAX;
@@ -79,9 +81,9 @@ struct OpsBatch {
       for (const Launch& l : P.launches) {
         if (l.count <= 0) continue;
         if (l.kind == L_POTRF)
-          launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag);
+          launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag, P.potrf_units[(size_t)l.first]);
         else if (l.kind == L_CHAIN)
-          launch_chain_panel(st, d_chain + l.first, l.count, base, d_dinv, d_flag);
+          launch_chain_panel(st, d_chain + l.first, l.count, base, d_dinv, d_flag, P.chain_units[(size_t)l.first]);
         else if (l.kind == L_PANEL)
           launch_panel(st, d_tiles + l.first, l.count, d_panel, base, d_dinv, d_pcnt, d_flag);
         else
