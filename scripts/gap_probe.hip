@@ -8,18 +8,27 @@
 #include <cstdio>
 #include <vector>
 
+// (each probe kernel spins ~8 us: with shorter kernels the HOST's launch rate is what is measured
+// -- 2.7 us per launch, 6.4 with an event record -- not the device's cost of a boundary)
+__device__ __forceinline__ void spin(int ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
 __global__ void k_small(double* p) {
+  spin(800);
   if (threadIdx.x == 0) p[blockIdx.x] += 1.0;
 }
 __global__ void k_lds(double* p) {
   extern __shared__ double sm[];
   sm[threadIdx.x] = p[threadIdx.x];
+  spin(800);
   __syncthreads();
   if (threadIdx.x == 0) p[blockIdx.x] += sm[1];
 }
 __global__ void k_static_lds(double* p) {
   __shared__ double sm[8192];
   sm[threadIdx.x] = p[threadIdx.x];
+  spin(800);
   __syncthreads();
   if (threadIdx.x == 0) p[blockIdx.x] += sm[1];
 }
@@ -62,8 +71,8 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipDeviceSynchronize());
       if (busy) {
-        hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask, d + (1 << 20), (int64_t)2048, 3000000);
-        hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask2, d + (1 << 23), (int64_t)2048, 3000000);
+        hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask, d + (1 << 20), (int64_t)2048, 12000000);
+        hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask2, d + (1 << 23), (int64_t)2048, 12000000);
       }
       CK(hipEventRecord(e0, st));
       for (int i = 0; i < N; ++i) {
@@ -79,7 +88,7 @@ int main() {
       CK(hipEventSynchronize(e1));
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep) printf("%-58s %s: %6.2f us per launch\n", what, busy ? "beside busy streams" : "alone              ", ms * 1e3 / N);
+      if (rep) printf("%-58s %s: %6.2f us per launch (of which ~8.0 the kernel)\n", what, busy ? "beside busy streams" : "alone              ", ms * 1e3 / N);
     }
     return 0;
   };
@@ -119,8 +128,8 @@ int main() {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipDeviceSynchronize());
         if (busy) {
-          hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask, d + (1 << 20), (int64_t)2048, 3000000);
-          hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask2, d + (1 << 23), (int64_t)2048, 3000000);
+          hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask, d + (1 << 20), (int64_t)2048, 12000000);
+          hipLaunchKernelGGL(k_busy, dim3(2048), dim3(256), 0, s_mask2, d + (1 << 23), (int64_t)2048, 12000000);
         }
         CK(hipEventRecord(e0, s_prio));
         CK(hipGraphLaunch(ge, s_prio));

@@ -9,6 +9,6 @@ for cfg in "$@"; do
   python - "$cfg" $OUT/ab_$i.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print("%-60s ms %.3f  GF %.0f  roofline kernel %.1f TF" % (sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["achieved"]), flush=True)
+print("%-60s ms %.3f  GF %.0f  roofline kernel %.1f TF  host submit %.2f ms" % (sys.argv[1], d["ms_per_step"], d["value"], d["roofline"]["achieved"], d["detail"].get("host_submit_ms_per_step", -1)), flush=True)
 PY
 done

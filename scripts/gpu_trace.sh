@@ -6,6 +6,6 @@ TAG=$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 for kv in $1; do export $kv; done
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$TAG -o t -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > $OUT/trace_$TAG.log 2>&1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$TAG -o t -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check ${BENCH_ARGS} > $OUT/trace_$TAG.log 2>&1
 echo rc=$?
 find $OUT/trace_$TAG -name "*kernel_trace.csv" -exec ls -la {} \;

@@ -554,6 +554,9 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   f->eo.deterministic = (flags & 4096) != 0;
   if (flags & 8192) f->eo.dist_top = 1;     // bit 13 / 14: top tree of a partitioned factorization
   if (flags & 16384) f->eo.dist_top = 0;    // distributed over the ranks / replicated on every rank  // bit 12: no atomics (buffer + ordered gather)
+  if (flags & 32768) f->eo.graph = 1;       // bit 15 / 16: HIP-graph replay, one chain in program order /
+  if (flags & 65536) f->eo.graph = 2;       // the DAG of the multi-stream program
+  if (flags & 131072) f->eo.graph = 0;      // bit 17: eager launches
   return 0;
 }
 

@@ -1,6 +1,7 @@
 // Engine implementation (HIP runtime API; compiled by hipcc as host code).
 #include "engine.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -242,6 +243,9 @@ static hipError_t borrow_streams(int device, int reserve, int ncu, bool far_on_b
     return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
   };
   StreamSet ss{device, reserve, (int)far_on_bulk, nullptr, nullptr, nullptr, true};
+  // (the chain stream confined to the reserved CUs -- the mirror image of the bulk mask -- was
+  // measured: 32.7 ms with 32 CUs, 26.6 with 64, 28.1 with 96 against 23.7: its launches at the
+  // lower levels have thousands of workgroups)
   if ((e = hipStreamCreateWithPriority(&ss.chain, hipStreamNonBlocking, prio_hi)) != hipSuccess) return e;
   if ((e = masked_stream(&ss.bulk)) != hipSuccess) return e;
   if (far_on_bulk) ss.far = ss.bulk;
@@ -298,6 +302,8 @@ int Engine::upload() {
   // launch-to-completion beside a masked bulk kernel, 30 us beside an unmasked one; masking
   // the FIRST bits instead gives erratic 13-450 us).  The wide stream (launches that have
   // the chip to themselves) is not masked.
+  graph_mode_ = opt_.graph;
+  if (const char* e = std::getenv("SPLLT_HIP_GRAPH")) graph_mode_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);
@@ -437,6 +443,8 @@ Engine::~Engine() {
   crumb("engine: destructor, draining streams");
   for (hipStream_t st : streams_)
     if (st) hipStreamSynchronize(st);
+  if (graph_exec_) hipGraphExecDestroy(graph_exec_);
+  if (graph_) hipGraphDestroy(graph_);
   crumb("engine: destructor, freeing");
   return_events(dag_events_, device_);       // (the streams are drained: nothing refers to them any more)
   hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
@@ -452,6 +460,24 @@ Engine::~Engine() {
   crumb("engine: destroyed");
 }
 
+// the kernel of one launch of the program, onto a stream or into a graph (LaunchSink)
+void Engine::emit_kernel(const Launch& l, const LaunchSink& sink, bool multi) {
+  if (l.kind == L_CHAIN) {
+    launch_chain_panel(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
+  } else if (l.kind == L_PANEL) {
+    launch_panel(sink, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
+  } else if (l.kind == L_GATHER) {
+    launch_gather(sink, d_gtiles_ + l.first, l.count, d_gitems_, d_L_, d_scratch_, d_relpos_, d_rlist_);
+  } else {
+    // multi-stream program: chain / side launches run at raised wave priority
+    const int prio = (multi && (l.stream == ST_CHAIN || l.stream == ST_SIDE)) ? chain_prio_ : 0;
+    int pad = 0;
+    if (multi && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
+    launch_update(sink, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
+                  d_relpos_, d_rlist_, d_dinv_, prio, pad, true, l.lat != 0);
+  }
+}
+
 int Engine::enqueue_launch(const Launch& l, bool serial) {
   hipStream_t st = serial ? stream_ : streams_[l.stream];
   if (!serial)
@@ -459,23 +485,127 @@ int Engine::enqueue_launch(const Launch& l, bool serial) {
       if (w >= 0) HIPCHK(hipStreamWaitEvent(st, dag_events_[w], 0), "stream wait");
   if (l.count > 0 && l.kind != L_EXCHANGE) {
     if (opt_.poison_lds) launch_poison_lds(st);
-    if (l.kind == L_CHAIN) {
-      launch_chain_panel(st, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
-    } else if (l.kind == L_PANEL) {
-      launch_panel(st, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
-    } else if (l.kind == L_GATHER) {
-      launch_gather(st, d_gtiles_ + l.first, l.count, d_gitems_, d_L_, d_scratch_, d_relpos_, d_rlist_);
-    } else {
-      // multi-stream program: chain / side launches run at raised wave priority
-      const bool multi = !serial && opt_.lookahead;
-      const int prio = (multi && (l.stream == ST_CHAIN || l.stream == ST_SIDE)) ? chain_prio_ : 0;
-      int pad = 0;
-      if (multi && l.overlap) pad = l.tile == 128 ? bulk_pad128_ : bulk_pad64_;
-      launch_update(st, l.tile, d_tiles_ + l.first, l.count, d_units_, d_bc_off_, d_bc_w_, d_L_,
-                    d_relpos_, d_rlist_, d_dinv_, prio, pad);
-    }
+    emit_kernel(l, LaunchSink(st), !serial && opt_.lookahead);
   }
   if (!serial && l.record >= 0) HIPCHK(hipEventRecord(dag_events_[l.record], st), "event record");
+  return 0;
+}
+
+// The whole factorization of one pattern as ONE HIP graph (analyse once,
+// factorize many -- reference spllt_kernels_mod.F90:2301-2364 re-initialises the same structure
+// for new values).  Built explicitly from the program (no stream capture: capturing the
+// multi-stream program crashed inside the runtime on ROCm 7.2): clear the arena, the "last
+// reader" counters and the flag, scatter the values, then one kernel node per launch, the flag's
+// way back to the host last.  Every address is fixed for the life of the engine; only the
+// content of d_val_ changes between replays.
+//   mode 1: a chain in program order (= the single-stream program: every node behind the one in
+//           front; 1.5 us per boundary instead of the eager path's 2.7 us, or 6.4 us where an
+//           event record sits between two launches -- scripts/gap_probe.hip)
+//   mode 2: the DAG of the multi-stream program: a node follows its predecessor on the same
+//           program stream and the launches that record the events it waits for
+int Engine::build_graph(int mode) {
+  if (graph_exec_) return 0;
+  if (!prog_.exchanges.empty() || opt_.poison_lds) return -98;   // single-GPU programs only
+  const Symbolic& S = *S_;
+  HIPCHK(hipGraphCreate(&graph_, 0), "hipGraphCreate");
+  std::vector<hipGraphNode_t> head;      // the prefix every launch follows
+  auto memset_node = [&](void* dst, int value, size_t words, const std::vector<hipGraphNode_t>& deps,
+                         hipGraphNode_t* out) -> hipError_t {
+    hipMemsetParams mp{};
+    mp.dst = dst;
+    mp.elementSize = 4;
+    mp.value = (unsigned)value;
+    mp.width = words;
+    mp.height = 1;
+    mp.pitch = words * 4;
+    return hipGraphAddMemsetNode(out, graph_, deps.data(), deps.size(), &mp);
+  };
+  hipGraphNode_t n_cnt = nullptr, n_flag = nullptr;
+  std::vector<hipGraphNode_t> pre;
+  {
+    // (in pieces of 4 GiB: 32-bit element counts somewhere below would not be a surprise)
+    const size_t words = (size_t)S.arena * 2, piece = (size_t)1 << 30;
+    for (size_t o = 0; o < words; o += piece) {
+      hipGraphNode_t n = nullptr;
+      HIPCHK(memset_node((int*)d_L_ + o, 0, std::min(piece, words - o), {}, &n), "graph memset arena");
+      pre.push_back(n);
+    }
+  }
+  if (!prog_.panel_units.empty()) {
+    HIPCHK(memset_node(d_panel_cnt_, 0, 2 * prog_.panel_units.size(), {}, &n_cnt), "graph memset counters");
+    pre.push_back(n_cnt);
+  }
+  HIPCHK(memset_node(d_flag_, INT_MAX, 1, {}, &n_flag), "graph memset flag");
+  pre.push_back(n_flag);
+  hipGraphNode_t n_scatter = nullptr;
+  {
+    LaunchSink sink;
+    sink.graph = graph_;
+    sink.deps = pre.data();
+    sink.ndeps = pre.size();
+    launch_scatter_val(sink, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
+    HIPCHK(sink.err, "graph scatter node");
+    n_scatter = sink.node;
+    if (!n_scatter) {     // (no entries: an empty node keeps the prefix in one piece)
+      HIPCHK(hipGraphAddEmptyNode(&n_scatter, graph_, pre.data(), pre.size()), "graph empty node");
+    }
+  }
+  const size_t nl = prog_.launches.size();
+  std::vector<hipGraphNode_t> recorder((size_t)std::max(1, prog_.nevents), nullptr);   // event id -> node
+  hipGraphNode_t last_on[ST_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipGraphNode_t last = n_scatter;
+  for (size_t i = 0; i < nl; ++i) {
+    const Launch& l = prog_.launches[i];
+    std::vector<hipGraphNode_t> deps;
+    auto add_dep = [&](hipGraphNode_t n) {
+      if (!n) return;
+      for (hipGraphNode_t d : deps)
+        if (d == n) return;
+      deps.push_back(n);
+    };
+    if (mode == 1) {
+      add_dep(last);
+    } else {
+      // (the wide and side streams are the chain stream, as in the eager engine)
+      const int sid = (l.stream == ST_WIDE || l.stream == ST_SIDE) ? ST_CHAIN : l.stream;
+      add_dep(last_on[sid] ? last_on[sid] : n_scatter);
+      for (int w : l.wait)
+        if (w >= 0) add_dep(recorder[(size_t)w]);
+    }
+    hipGraphNode_t node = nullptr;
+    if (l.count > 0) {
+      LaunchSink sink;
+      sink.graph = graph_;
+      sink.deps = deps.data();
+      sink.ndeps = deps.size();
+      emit_kernel(l, sink, mode == 2 && opt_.lookahead);
+      HIPCHK(sink.err, "graph kernel node");
+      node = sink.node;
+    } else {
+      HIPCHK(hipGraphAddEmptyNode(&node, graph_, deps.data(), deps.size()), "graph marker node");
+    }
+    last = node;
+    const int sid = (l.stream == ST_WIDE || l.stream == ST_SIDE) ? ST_CHAIN : l.stream;
+    last_on[sid] = node;
+    if (l.record >= 0) recorder[(size_t)l.record] = node;
+  }
+  {
+    std::vector<hipGraphNode_t> deps;
+    if (mode == 1) {
+      deps.push_back(last);
+    } else {
+      auto add = [&](hipGraphNode_t n) {
+        if (n && std::find(deps.begin(), deps.end(), n) == deps.end()) deps.push_back(n);
+      };
+      for (hipGraphNode_t n : last_on) add(n);
+      if (prog_.final_event >= 0) add(recorder[(size_t)prog_.final_event]);
+      if (deps.empty()) deps.push_back(n_scatter);
+    }
+    hipGraphNode_t n_out = nullptr;
+    HIPCHK(hipGraphAddMemcpyNode1D(&n_out, graph_, deps.data(), deps.size(), h_flag_, d_flag_, sizeof(int),
+                                   hipMemcpyDeviceToHost), "graph flag read");
+  }
+  HIPCHK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0), "hipGraphInstantiate");
   return 0;
 }
 
@@ -497,6 +627,14 @@ int Engine::finish_enqueue() {
 
 int Engine::enqueue_program() {
   const Symbolic& S = *S_;
+  if (graph_mode_ > 0 && prog_.exchanges.empty() && !opt_.poison_lds) {
+    int rc = build_graph(graph_mode_);
+    if (rc) return rc;
+    stats_.launches = (int)prog_.launches.size() + 1;
+    HIPCHK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
+    awaiting_exchange_ = false;
+    return 0;
+  }
   if (opt_.nranks > 1) {
     for (const auto& r : zero_ranges_)
       HIPCHK(hipMemsetAsync(d_L_ + r.first, 0, sizeof(double) * (size_t)r.second, stream_), "memset arena");

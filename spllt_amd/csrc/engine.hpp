@@ -30,6 +30,9 @@ struct EngineOptions {
                            // problem is latency-bound (schedule.hpp), else 0)
   int zones = -1;          // zone pipeline of the inter-node updates (1 / 0; -1: when latency-bound)
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
+  int graph = 0;           // HIP-graph replay of the factorization (single GPU): 0 eager launches, 1 one
+                           // chain of kernel nodes in program order, 2 the DAG of the multi-stream
+                           // program (env SPLLT_HIP_GRAPH overrides)
 };
 
 struct FactorStats {
@@ -104,6 +107,8 @@ class Engine {
   int post_exchange(const Launch& X);         // unpack + record
   int finish_enqueue();
   int enqueue_launch(const Launch& l, bool serial);
+  void emit_kernel(const Launch& l, const struct LaunchSink& sink, bool multi);
+  int build_graph(int mode);
   int fail(int code, const char* what, hipError_t e);
   // hipStreamSynchronize with a deadline (SPLLT_HIP_TIMEOUT_S, default 180 s; 0 = wait forever):
   // a stream that does not drain makes the call FAIL with a report of the first launch of the
@@ -127,6 +132,9 @@ class Engine {
   int bulk_pad128_ = 0, bulk_pad64_ = 0;
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
+  int graph_mode_ = 0;
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t graph_exec_ = nullptr;
   bool pending_ = false;
   bool awaiting_exchange_ = false;
   size_t cur_x_ = 0;                // launch index of the exchange the engine waits for

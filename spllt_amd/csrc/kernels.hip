@@ -31,6 +31,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <tuple>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -48,6 +49,27 @@
 namespace spx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// launch, or add as a kernel node (LaunchSink)
+template <class... KArgs, class... Args>
+static void emit(const LaunchSink& s, void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, Args... args) {
+  if (!s.graph) {
+    hipLaunchKernelGGL(kernel, grid, block, lds, s.stream, args...);
+    return;
+  }
+  std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);
+  void* params[sizeof...(KArgs)];
+  size_t i = 0;
+  std::apply([&](auto&... v) { ((params[i++] = (void*)&v), ...); }, vals);
+  hipKernelNodeParams kp{};
+  kp.func = reinterpret_cast<void*>(kernel);
+  kp.gridDim = grid;
+  kp.blockDim = block;
+  kp.sharedMemBytes = lds;
+  kp.kernelParams = params;
+  kp.extra = nullptr;
+  s.err = hipGraphAddKernelNode(&s.node, s.graph, s.deps, s.ndeps, &kp);
+}
 
 // ---------------------------------------------------------------------------
 // a8: L[dst[i]] = val[src[i]]  (assignment; the arena was zeroed beforehand)
@@ -1855,12 +1877,12 @@ void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_li
                      col_list, cls, ndiag, buffer);
 }
 
-void launch_scatter_val(hipStream_t st, double* L, const double* val, const int64_t* dst,
+void launch_scatter_val(const LaunchSink& st, double* L, const double* val, const int64_t* dst,
                         const int64_t* src, int64_t n) {
   if (n <= 0) return;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_scatter_val, dim3((unsigned)blocks), dim3(256), 0, st, L, val, dst, src, n);
+  emit(st, k_scatter_val, dim3((unsigned)blocks), dim3(256), 0, L, val, dst, src, n);
 }
 
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
@@ -1869,13 +1891,13 @@ void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double*
   hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag, unit0);
 }
 
-void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
                         int* flag, const ChainUnit& unit0) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_chain_potrf, dim3((unsigned)count), dim3(256), 0, st, units, L, dinv, flag, unit0);
+  emit(st, k_chain_potrf, dim3((unsigned)count), dim3(256), 0, units, L, dinv, flag, unit0);
 }
 
-void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
+void launch_panel(const LaunchSink& st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
                   double* dinv, int* counters, int* flag) {
   if (count <= 0) return;
   const unsigned lds = (unsigned)(sizeof(PotrfShared) + sizeof(double) * 2 * 64 * TLD);
@@ -1886,8 +1908,7 @@ void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const Pan
     (void)hipFuncSetAttribute((const void*)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_dev = dev;
   }
-  hipLaunchKernelGGL(k_panel, dim3((unsigned)count), dim3(kPanelThreads), lds, st, tiles, units, L, dinv, counters,
-                     flag);
+  emit(st, k_panel, dim3((unsigned)count), dim3(kPanelThreads), lds, tiles, units, L, dinv, counters, flag);
 }
 
 // ---------------------------------------------------------------------------
@@ -1930,10 +1951,10 @@ __global__ __launch_bounds__(256) void k_gather(const GatherTile* __restrict__ t
   }
 }
 
-void launch_gather(hipStream_t st, const GatherTile* tiles, int64_t count, const GatherItem* items,
+void launch_gather(const LaunchSink& st, const GatherTile* tiles, int64_t count, const GatherItem* items,
                    double* L, const double* scratch, const int* relpos, const int* rlist) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)count), dim3(256), 0, st, tiles, items, L, scratch, relpos, rlist);
+  emit(st, k_gather, dim3((unsigned)count), dim3(256), 0, tiles, items, L, scratch, relpos, rlist);
 }
 
 // multi-GPU: the "not positive definite" flag travels with the exchange buffer.  Before the
@@ -1975,11 +1996,30 @@ void launch_poison_lds(hipStream_t st) {
   hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), 160 * 1024, st, (int*)nullptr);
 }
 
-void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
+void launch_update(const LaunchSink& st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv, int prio,
-                   int lds_pad, bool allow_dma) {
+                   int lds_pad, bool allow_dma, bool latency) {
   if (count <= 0) return;
+  static const int lat_bk = [] { const char* e = std::getenv("SPLLT_LAT_BK"); return e ? std::atoi(e) : 0; }();
+  if (latency && lat_bk == 64 && (tile == 64 || tile == 32)) {
+    thread_local int attr_dev3 = -1;
+    int dev3 = 0;
+    (void)hipGetDevice(&dev3);
+    if (dev3 != attr_dev3) {
+      (void)hipFuncSetAttribute((const void*)k_update<64, 64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_update<32, 64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_dev3 = dev3;
+    }
+    const unsigned lds = (unsigned)(sizeof(double) * 2 * UPD_STAGES * tile * (64 + UPD_LDK_PAD));
+    if (tile == 64)
+      emit(st, k_update<64, 64, 2, 2>, dim3((unsigned)count), dim3(256), lds, tiles, units, bc_off, bc_w, L, relpos,
+           rlist, dinv, prio);
+    else
+      emit(st, k_update<32, 64, 2, 2>, dim3((unsigned)count), dim3(256), lds, tiles, units, bc_off, bc_w, L, relpos,
+           rlist, dinv, prio);
+    return;
+  }
   // lds_pad: extra (unused) dynamic LDS that caps the workgroups per CU of a
   // trailing-update launch so that panel-chain kernels find room beside it
   // dynamic LDS: the operand stages of the tile (+ the optional pad)
@@ -2023,23 +2063,22 @@ void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count
       attr_dev2 = dev2;
     }
     if (tile == 128)
-      hipLaunchKernelGGL(k_update_dma128, dim3((unsigned)count), dim3(512), lds, st, tiles, units, bc_off,
-                         bc_w, L, relpos, rlist, dinv, prio);
+      emit(st, k_update_dma128, dim3((unsigned)count), dim3(512), lds, tiles, units, bc_off, bc_w, L, relpos, rlist,
+           dinv, prio);
     else
-      hipLaunchKernelGGL(k_update_dma64, dim3((unsigned)count), dim3(256), lds, st, tiles, units, bc_off,
-                         bc_w, L, relpos, rlist, dinv, prio);
+      emit(st, k_update_dma64, dim3((unsigned)count), dim3(256), lds, tiles, units, bc_off, bc_w, L, relpos, rlist,
+           dinv, prio);
     return;
   }
   if (tile == 128)
-    hipLaunchKernelGGL((k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>), dim3((unsigned)count),
-                       dim3(64 * UPD128_WM * UPD128_WN), pad, st, tiles,
-                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+    emit(st, k_update<128, UPD128_BK, UPD128_WM, UPD128_WN>, dim3((unsigned)count), dim3(64 * UPD128_WM * UPD128_WN),
+         pad, tiles, units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
   else if (tile == 64)
-    hipLaunchKernelGGL((k_update<64, 16, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
-                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+    emit(st, k_update<64, 16, 2, 2>, dim3((unsigned)count), dim3(256), pad, tiles, units, bc_off, bc_w, L, relpos,
+         rlist, dinv, prio);
   else
-    hipLaunchKernelGGL((k_update<32, 32, 2, 2>), dim3((unsigned)count), dim3(256), pad, st, tiles,
-                       units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
+    emit(st, k_update<32, 32, 2, 2>, dim3((unsigned)count), dim3(256), pad, tiles, units, bc_off, bc_w, L, relpos,
+         rlist, dinv, prio);
 }
 
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,

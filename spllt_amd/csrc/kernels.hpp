@@ -9,30 +9,45 @@
 
 namespace spx {
 
-void launch_scatter_val(hipStream_t st, double* L, const double* val, const int64_t* dst,
+// Where a kernel goes: onto a stream (eager), or into a HIP graph as a kernel node behind
+// `deps` (graph construction, Engine::build_graph; `node` returns the node, `err` the status).
+struct LaunchSink {
+  hipStream_t stream = nullptr;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  mutable hipGraphNode_t node = nullptr;
+  mutable hipError_t err = hipSuccess;
+  LaunchSink() = default;
+  LaunchSink(hipStream_t st) : stream(st) {}   // every wrapper below also takes a plain stream
+};
+
+void launch_scatter_val(const LaunchSink& st, double* L, const double* val, const int64_t* dst,
                         const int64_t* src, int64_t n);
 // (unit0 = host copy of units[0]: travels with the kernel arguments)
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag, const PotrfUnit& unit0);
 // one step of the panel chain per workgroup (ChainUnit): POTRF of the panel + its inverse
-void launch_chain_panel(hipStream_t st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
                         int* flag, const ChainUnit& unit0);
 // one whole panel step per launch (PanelUnit; tiles: unit, ti = 64-row block below the panel)
 // counters: two zero-initialised ints per panel unit (left zero again by the launch)
-void launch_panel(hipStream_t st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
+void launch_panel(const LaunchSink& st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
                   double* dinv, int* counters, int* flag);
 // deterministic assembly of buffered inter-node update blocks (GatherTile / GatherItem)
-void launch_gather(hipStream_t st, const GatherTile* tiles, int64_t count, const GatherItem* items,
+void launch_gather(const LaunchSink& st, const GatherTile* tiles, int64_t count, const GatherItem* items,
                    double* L, const double* scratch, const int* relpos, const int* rlist);
 // multi-GPU: not-positive-definite flag <-> extra element of the exchange buffer
 void launch_flag_pack(hipStream_t st, const int* flag, double* slot);
 void launch_flag_unpack(hipStream_t st, const double* slot, int* flag);
 // debug: fill the LDS of every CU with signalling NaNs
 void launch_poison_lds(hipStream_t st);
-void launch_update(hipStream_t st, int tile, const UpdTile* tiles, int64_t count,
+void launch_update(const LaunchSink& st, int tile, const UpdTile* tiles, int64_t count,
                    const UpdUnit* units, const int64_t* bc_off, const int* bc_w, double* L,
                    const int* relpos, const int* rlist, const double* dinv, int prio = 0,
-                   int lds_pad = 0, bool allow_dma = true);
+                   int lds_pad = 0, bool allow_dma = true, bool latency = false);
+// (latency: a small launch on the critical path -- 64 columns of K per LDS step instead of 16, so
+// that a tile makes a quarter of the dependent round trips to memory)
 // (allow_dma = false: the register-staged kernels -- for operands in caller-owned buffers without
 // slack behind them: the DMA kernels load whole 16-column chunks)
 void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_index,

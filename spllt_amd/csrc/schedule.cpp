@@ -10,7 +10,7 @@ namespace spx {
 namespace {
 
 struct Edge {
-  int stream = 0, wait0 = -1, wait1 = -1, wait2 = -1, record = -1, overlap = 0;
+  int stream = 0, wait0 = -1, wait1 = -1, wait2 = -1, record = -1, overlap = 0, lat = 0;
 };
 
 static int64_t env_int(const char* name, int64_t dflt) {
@@ -152,6 +152,7 @@ struct Builder {
       }
       L.record = pass == last_nonempty ? e.record : -1;
       L.overlap = e.overlap;
+      L.lat = e.lat;
       P.tiles.insert(P.tiles.end(), tv.begin(), tv.end());
       P.launches.push_back(L);
     }
@@ -695,6 +696,7 @@ struct Builder {
             {
               Edge e = edge(ST_CHAIN);
               e.record = evD;        // (an empty launch still forwards the event)
+              e.lat = 1;
               emit_gemm(lev, us, fl, false, e);
             }
           }
@@ -805,6 +807,7 @@ struct Builder {
           P.flops_update += fl_n1 + fl_n2 + fl_bulk;
           if (!us_n1.empty()) {
             Edge e = edge(ST_CHAIN);
+            e.lat = 1;
             if (la) {
               if (to_next_bcol) {
                 e.wait1 = evB_c1;      // bulk (c-1 -> c+1..) writes the same entries

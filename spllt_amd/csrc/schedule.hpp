@@ -155,6 +155,9 @@ struct Launch {
   int wait[4] = {-1, -1, -1, -1};
   int record = -1;
   int overlap = 0;  // 1: bulk launch that runs beside a panel chain (engine may cap its CU share)
+  int lat = 0;      // 1: a step of the panel chain (TRSM, in-panel update, update of the next block
+                    // column): few tiles, the next step waits for it -- the engine may pick a
+                    // kernel variant built for latency instead of throughput
   void add_wait(int ev) {
     if (ev < 0) return;
     for (int& w : wait) {

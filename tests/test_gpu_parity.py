@@ -564,6 +564,31 @@ def test_engine_variants_match_oracle(flags, cb):
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
+@pytest.mark.parametrize("flags", [32768, 65536, 65536 | 4096, 32768 | 512, 65536 | 2048])
+def test_graph_replay_matches_oracle(flags):
+    """SURVEY 8(f) row f1, analyse once / factorize many (reference kernels_mod:2301-2364): the
+    factorization of a pattern as ONE HIP graph built from the program tables (flag bit 15: a
+    chain of kernel nodes in program order; bit 16: the DAG of the multi-stream program), replayed
+    for new values of the same pattern.  Every replay against the oracle."""
+    A = matgen.nd_like((12, 11, 10), 2)
+    f, val = make_case(A, nb=160, nemin=16, panel_width=32, engine_flags=flags)
+    for scale in (1.0, 3.0, 0.5):          # same pattern, new values: the graph is replayed
+        v = val * scale
+        got = f.factor(v).wait().get_factor()
+        o, rc = oracle_factor(f, v)
+        assert rc == 0
+        assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = (A * 0.5) @ np.ones(f.n)
+    assert bwd_err(A * 0.5, f.solve(b), b) <= 1e-14
+    # a matrix that is not positive definite is reported through the graph's own copy of the flag
+    bad = val.copy()
+    bad[0] = -1.0
+    with pytest.raises(api.SplltError) as ei:
+        f.factor(bad).wait()
+    assert ei.value.flag == -20
+    f.close()
+
+
 @pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson3d(40), 384), (lambda: matgen.fe27((20, 20, 18), 3), 256)])
 def test_fused_panel_launches_larger_than_the_chip(gen, nb, monkeypatch):
     """k_panel: the diagonal block and the next pivot rows are read by every workgroup of a
