@@ -78,9 +78,9 @@ def roofline_from_profile(f, val):
     direct / scatter / TRSM epilogue) with the largest total time.  achieved =
     algorithmic flops of all its launches / the sum of their durations, measured live with
     HIP events on the stream each launch runs on.  Two figures:
-      frac            launches serialized on one stream: the kernel alone on the chip
-      frac_in_program the same launches inside the real multi-stream program (beside the
-                      panel chains and the other update streams): what the program gets"""
+      frac        the launches inside the real multi-stream program (beside the panel chains and
+                  the other update streams): what the program gets
+      frac_alone  the same launches serialized on one stream: the kernel alone on the chip"""
     # two passes, per-launch minimum: a single pass occasionally shows one launch
     # stalled by tens of ms (host/driver hiccup between its two event records)
     ms = np.minimum(f.profile(val), f.profile(val))
@@ -102,13 +102,16 @@ def roofline_from_profile(f, val):
     t_s, fl, nl, t_prog = per[T][0] * 1e-3, per[T][1], per[T][2], per[T][3] * 1e-3
     ach = fl / t_s / 1e12 if t_s > 0 else 0.0
     ach_prog = fl / t_prog / 1e12 if t_prog > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": UPDATE_KERNELS[T], "achieved": round(ach, 3),
+    # achieved / frac: INSIDE the program (what the factorization gets from the kernel: every launch
+    # bracketed by two events on its own stream, beside whatever runs on the other streams);
+    # achieved_alone / frac_alone: the same launches serialized, the kernel alone on the chip
+    roof = {"bound": "mfma", "kernel": UPDATE_KERNELS[T], "achieved": round(ach_prog, 3),
             "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
-            "achieved_in_program": round(ach_prog, 3),
-            "frac_in_program": round(ach_prog / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launches": nl, "avg_launch_ms": round(per[T][0] / max(nl, 1), 4),
-            "avg_launch_ms_in_program": round(per[T][3] / max(nl, 1), 4)}
+            "frac": round(ach_prog / FP64_MFMA_PEAK_TFLOPS, 4),
+            "achieved_alone": round(ach, 3),
+            "frac_alone": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": nl, "avg_launch_ms": round(per[T][3] / max(nl, 1), 4),
+            "avg_launch_ms_alone": round(per[T][0] / max(nl, 1), 4)}
     return roof, table, ms
 
 
@@ -164,7 +167,7 @@ def run_extra_config(cfg_name, steps=2):
            "resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
            "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x))),
            "dominant_kernel": roof["kernel"], "dominant_tflops": roof["achieved"],
-           "dominant_frac": roof["frac"], "dominant_frac_in_program": roof["frac_in_program"]}
+           "dominant_frac": roof["frac"], "dominant_frac_alone": roof["frac_alone"]}
     f.close()
     del dval
     torch.cuda.empty_cache()
@@ -198,8 +201,19 @@ def cpu_baseline(f, val, flops, threads):
         t0 = time.time()
         rc = o.factorize(val, threads)
         dt = min(dt, time.time() - t0) if dt is not None else time.time() - t0
-    return o, {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads,
-               "kind": "port", "seconds": round(dt, 3), "blas": blas, "rc": rc}
+    out = {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads,
+           "kind": "port", "seconds": round(dt, 3), "blas": blas, "rc": rc}
+    if threads > 1:
+        # t_cpu_seq beside t_cpu_omp (the reference drivers' window,
+        # drivers/spllt_omp.F90:185-192): the same oracle, one thread, one run
+        t0 = time.time()
+        rc1 = o.factorize(val, 1)
+        dt1 = time.time() - t0
+        out["seq_seconds"] = round(dt1, 3)
+        out["seq_value"] = round(flops / dt1 / 1e9, 2)
+        out["seq_rc"] = rc1
+        o.factorize(val, threads)     # (the check below reads the parallel run's factor)
+    return o, out
 
 
 def main():
@@ -351,7 +365,8 @@ def main():
         f.close()
         del dval
         torch.cuda.empty_cache()
-        for other in ("poisson3d_128", "serena_like"):
+        # (flan_like = BASELINE config 4 on one GPU: 32.7 GB of factor, ~0.8 s per factorization)
+        for other in ("poisson3d_128", "serena_like") + (() if os.environ.get("SPLLT_NO_FLAN") else ("flan_like",)):
             if other != args.config:
                 extra.append(run_extra_config(other))
     out = {

@@ -69,6 +69,24 @@ int spllt_scatter_block_hip(void *stream, int s_m, int s_n, const int *rsrc_inde
 int spllt_init_lfact_hip(void *stream, double *L, const double *val, const int64_t *dst,
                          const int64_t *src, int64_t n);
 
+/* ---- (1b) matrix file readers ------------------------
+ * What the reference keeps beside the path for its drivers: MatrixMarket coordinate files
+ * (src/spllt_mod.F90:426-491 mm_double_read + :543-620 coo_to_csc_double) and Rutherford-Boeing
+ * files of assembled symmetric matrices (SPRAL rb_read as the drivers call it,
+ * drivers/spllt_omp.F90:78-85).  Both return the LOWER triangle as 1-based CSC with sorted
+ * rows -- the arguments of spllt_analyse / spllt_factor -- in malloc'ed arrays that
+ * spllt_hip_free_matrix releases.  values: 0 = as in the file (a pattern-only file is an error),
+ * 3 = the drivers' rb_options%values = 3: off-diagonal values as in the file, or made up
+ * (uniform in (-1, 1), splitmix64 from `seed`; the reference: SPRAL random_real,
+ * spllt_mod.F90:480-485) for a pattern-only file, every diagonal entry 1 + the sum of the
+ * |off-diagonal entries| of its row.  A general MatrixMarket matrix is read as (A + A^T) / 2.
+ * Returns 0 or an SPLLT error flag (message on stderr). */
+int spllt_hip_read_rb(const char *path, int values, int seed, int *n, int *nnz, int **ptr, int **row,
+                      double **val);
+int spllt_hip_read_mm(const char *path, int values, int seed, int *n, int *nnz, int **ptr, int **row,
+                      double **val);
+void spllt_hip_free_matrix(int *ptr, int *row, double *val);
+
 /* ---- (2) engine control / introspection ----------------------------------- */
 
 typedef struct {

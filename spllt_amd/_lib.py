@@ -56,6 +56,7 @@ HIP_SYMBOLS = [
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
     "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program",
+    "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix",
 ]
 
 _lib = None
@@ -167,5 +168,11 @@ def load():
     lib.spllt_scatter_block_hip.restype = C.c_int
     lib.spllt_init_lfact_hip.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
     lib.spllt_init_lfact_hip.restype = C.c_int
+    ip, ipp, dpp = C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_double))
+    for fn in (lib.spllt_hip_read_rb, lib.spllt_hip_read_mm):
+        fn.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, ip, ipp, ipp, dpp]
+        fn.restype = C.c_int
+    lib.spllt_hip_free_matrix.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    lib.spllt_hip_free_matrix.restype = None
     _lib = lib
     return lib

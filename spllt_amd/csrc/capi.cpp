@@ -39,6 +39,7 @@ struct Fkeep {
   double* workspace = nullptr;
   long worksize = 0;
   double* xbuf = nullptr;  // multi-GPU exchange buffer (caller-owned device memory)
+  bool dead = false;       // a submission never returned: the engine belongs to the stuck helper thread
 };
 
 std::mutex g_mu;
@@ -59,6 +60,7 @@ void fill_info(const Symbolic& S, spllt_inform_t* info) {
 }
 
 int do_wait(Fkeep* f) {
+  if (f->dead) return SPLLT_ERROR_HIP;    // (its engine belongs to a submission that never returned)
   if (!f->eng) return f->last_flag;
   if (f->eng->pending()) {
     int rc = f->eng->wait();
@@ -218,19 +220,32 @@ void factor_impl(void* akeep, void* fkeep, int nnz, const double* val, bool dev,
     if (info) info->flag = SPLLT_ERROR_PARAMETER;
     return;
   }
-  if (f->eng && f->eng->pending()) do_wait(f);
-  if (!f->eng) {
-    f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
-    if (!f->eng) { if (info) info->flag = SPLLT_ERROR_ALLOCATION; return; }
-    f->eng->set_exchange_buffer(f->xbuf);
-  }
-  if (f->eng->status()) {
-    f->last_flag = f->eng->status();
-    f->last_error = f->eng->error();
-    if (info) info->flag = f->last_flag;
+  if (f->dead) {          // an earlier submission of this handle never returned (below)
+    if (info) info->flag = SPLLT_ERROR_HIP;
     return;
   }
-  int rc = dev ? f->eng->factor_async_dev(val, nnz) : f->eng->factor_async(val, nnz);
+  if (f->eng && f->eng->pending()) do_wait(f);
+  // engine creation and submission on the helper thread, under the deadline (engine.cpp)
+  std::string why;
+  int rc = run_with_deadline([f, dev, val, nnz]() -> int {
+    if (!f->eng) {
+      f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+      if (!f->eng) return SPLLT_ERROR_ALLOCATION;
+      f->eng->set_exchange_buffer(f->xbuf);
+    }
+    if (f->eng->status()) return f->eng->status();
+    return dev ? f->eng->factor_async_dev(val, nnz) : f->eng->factor_async(val, nnz);
+  }, &why);
+  if (!why.empty()) {
+    // the helper thread may still be inside the engine: the handle is dead, its engine is never
+    // touched again (spllt_deallocate_fkeep leaks it)
+    f->dead = true;
+    f->last_flag = SPLLT_ERROR_HIP;
+    f->last_error = why;
+    if (info) info->flag = SPLLT_ERROR_HIP;
+    return;
+  }
+  if (rc == SPLLT_ERROR_ALLOCATION && !f->eng) { if (info) info->flag = rc; return; }
   f->last_flag = rc;
   f->hostL_valid = false;
   if (rc == 0) {
@@ -443,6 +458,12 @@ void spllt_deallocate_fkeep(void** fkeep, int* stat) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_pending.erase(std::remove(g_pending.begin(), g_pending.end(), f), g_pending.end());
   }
+  if (f->dead) {
+    // a submission of this handle never returned: the helper thread may still be inside the
+    // engine (and reads the symbolic structure through it) -- both are leaked
+    (void)f->eng.release();
+    (void)new std::shared_ptr<Symbolic>(f->S);
+  }
   delete f;
   *fkeep = nullptr;
 }
@@ -570,15 +591,8 @@ int spllt_hip_set_chain_block(void* fkeep, int chain_block) {
 
 // The program of a handle that has no engine (yet): built on the host, no GPU needed.
 static void build_local_program(Fkeep* f, Program& local) {
-  ScheduleOptions so;
-  so.pw = f->eo.pw;
-  so.tile = f->eo.tile;
-  so.cb = f->eo.cb;
-  so.lookahead = f->eo.lookahead;
-  so.slice_between = f->eo.slice_between;
-  so.deterministic = f->eo.deterministic;
-  so.fused_panel = f->eo.fused_panel;
-  so.zones = f->eo.zones < 0 ? latency_bound(*f->S, std::min(f->eo.pw, kPanelMax)) : f->eo.zones != 0;
+  EngineOptions eo = f->eo;                 // (the handle's options stay unresolved)
+  ScheduleOptions so = schedule_options(*f->S, eo);
   std::vector<int> owner, top_owner;
   partition_options(*f->S, f->eo, owner, top_owner, so);
   build_program(*f->S, so, local);

@@ -2,7 +2,11 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <climits>
@@ -53,8 +57,9 @@ struct TableStager {
   }
   template <class Tp>
   void add(Tp** dptr, const std::vector<Tp>& v) { add(dptr, v.data(), v.size()); }
-  hipError_t commit(char** blob) {
-    hipError_t e = hipMalloc((void**)blob, std::max<size_t>(host.size(), 8));
+  template <class Alloc>
+  hipError_t commit(char** blob, Alloc&& alloc) {
+    hipError_t e = alloc((void**)blob, std::max<size_t>(host.size(), 8));
     if (e != hipSuccess) return e;
     if (!host.empty()) e = hipMemcpy(*blob, host.data(), host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
@@ -80,11 +85,171 @@ static void return_pinned_word(int* p) {
   if (p) g_pinned_words.push_back(p);
 }
 
-int Engine::sync_stream(hipStream_t st, const char* what) {
+// ---------------------------------------------------------------------------
+// Process-wide resource pools.  An engine takes its runtime objects from here and hands them
+// back; nothing is created or destroyed per engine that can be reused:
+//   * streams and events (below): creating and destroying a CU-masked stream is creating and
+//     destroying a hardware queue (the driver unmaps and remaps every queue of the process for
+//     it) -- the one thing the engines of round 2 did per factorization that nothing else in
+//     the process does, see DESIGN.md "Hangs";
+//   * device buffers: hipFree synchronises the WHOLE device -- every other live engine's
+//     streams, and the caller's -- so the buffers of a closed engine are kept (up to a cap) for
+//     the next one;
+//   * pinned staging buffers for the host-to-device copy of val.
+// pools_teardown() (atexit, registered on first use, i.e. after the HIP runtime has registered
+// its own handlers and therefore run BEFORE them) drains and destroys all of it, so that the
+// runtime does not unload with live CU-masked queues (the exit crash of the profiled runs).
+// ---------------------------------------------------------------------------
+namespace {
+std::mutex g_pool_mu;
+struct DevBuf { void* p; size_t bytes; int device; };
+std::vector<DevBuf> g_dev_cache;
+size_t g_dev_cached_bytes = 0;
+struct PinBuf { void* p; size_t bytes; };
+std::vector<PinBuf> g_pin_cache;
+bool g_teardown_registered = false;
+void pools_teardown();
+void register_teardown() {
+  if (!g_teardown_registered) {
+    g_teardown_registered = true;
+    std::atexit(pools_teardown);
+  }
+}
+size_t dev_cache_cap() {
+  static const size_t cap = [] {
+    const char* e = std::getenv("SPLLT_HIP_CACHE_MB");
+    return (size_t)(e && *e ? std::atoll(e) : 2048) << 20;
+  }();
+  return cap;
+}
+}  // namespace
+
+// a device buffer of at least `bytes`: from the cache (smallest fit that wastes at most half), else hipMalloc
+static hipError_t dev_alloc(void** p, size_t bytes, int device) {
+  bytes = std::max<size_t>(bytes, 256);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    register_teardown();
+    int best = -1;
+    for (size_t i = 0; i < g_dev_cache.size(); ++i) {
+      const DevBuf& b = g_dev_cache[i];
+      if (b.device != device || b.bytes < bytes || b.bytes > 2 * bytes + (1 << 20)) continue;
+      if (best < 0 || b.bytes < g_dev_cache[(size_t)best].bytes) best = (int)i;
+    }
+    if (best >= 0) {
+      *p = g_dev_cache[(size_t)best].p;
+      g_dev_cached_bytes -= g_dev_cache[(size_t)best].bytes;
+      g_dev_cache.erase(g_dev_cache.begin() + best);
+      return hipSuccess;
+    }
+  }
+  return hipMalloc(p, bytes);
+}
+// back into the cache (the caller has drained every stream that used it); beyond the cap, or
+// when the size is not known to the cache, it is freed for real
+static void dev_release(void* p, size_t bytes, int device) {
+  if (!p) return;
+  bytes = std::max<size_t>(bytes, 256);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_dev_cached_bytes + bytes <= dev_cache_cap()) {
+      g_dev_cache.push_back({p, bytes, device});
+      g_dev_cached_bytes += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+static hipError_t pin_alloc(void** p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    register_teardown();
+    for (size_t i = 0; i < g_pin_cache.size(); ++i)
+      if (g_pin_cache[i].bytes == bytes) {
+        *p = g_pin_cache[i].p;
+        g_pin_cache.erase(g_pin_cache.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+static void pin_release(void* p, size_t bytes) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pin_cache.push_back({p, bytes});
+}
+
+double hip_deadline_s() {
   static const double limit_s = [] {
     const char* e = std::getenv("SPLLT_HIP_TIMEOUT_S");
     return (e && *e) ? std::atof(e) : 180.0;
   }();
+  return limit_s;
+}
+
+// hipEventSynchronize with the deadline of sync_stream
+int Engine::wait_event(hipEvent_t ev, const char* what) {
+  const double limit_s = hip_deadline_s();
+  if (limit_s <= 0) {
+    hipError_t e = hipEventSynchronize(ev);
+    return e == hipSuccess ? 0 : fail(kErrHip, what, e);
+  }
+  const double t0 = now_ms();
+  for (;;) {
+    hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(kErrHip, what, q);
+    const double dt = now_ms() - t0;
+    if (dt > limit_s * 1e3) break;
+    if (dt > 5.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else std::this_thread::yield();
+  }
+  status_ = kErrHip;
+  err_ = std::string(what) + ": the copy engine did not finish within " + std::to_string((int)limit_s) + " s";
+  poisoned_ = true;
+  std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
+  return kErrHip;
+}
+
+// val (pageable user memory) -> d_val_ through two pinned 16 MiB buffers: the host copies chunk
+// k + 1 while the DMA of chunk k flies; every wait has the deadline.
+int Engine::stage_val(const double* val_host, int64_t nnz) {
+  const size_t bytes = sizeof(double) * (size_t)nnz;
+  // (two sizes of staging buffers: pinning 2 x 16 MiB costs ~2 ms the first time, which a small
+  // problem need not pay)
+  const size_t chunk = bytes <= kH2dSmall ? kH2dSmall : kH2dChunk;
+  if (h2d_chunk_ != chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (h2d_busy_[i]) { int rc = wait_event(h2d_ev_[i], "val H2D staging"); if (rc) return rc; h2d_busy_[i] = false; }
+      if (h2d_buf_[i]) pin_release(h2d_buf_[i], h2d_chunk_);
+      h2d_buf_[i] = nullptr;
+    }
+    h2d_chunk_ = chunk;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!h2d_buf_[i]) HIPCHK(pin_alloc(&h2d_buf_[i], chunk), "hipHostMalloc(staging)");
+    if (!h2d_ev_[i]) HIPCHK(hipEventCreateWithFlags(&h2d_ev_[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  const char* src = reinterpret_cast<const char*>(val_host);
+  char* dst = reinterpret_cast<char*>(d_val_);
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += chunk, ++k) {
+    const int i = k & 1;
+    const size_t len = std::min(chunk, bytes - off);
+    if (h2d_busy_[i]) {               // the buffer's previous DMA (this call's or the last one's)
+      int rc = wait_event(h2d_ev_[i], "val H2D staging");
+      if (rc) return rc;
+    }
+    std::memcpy(h2d_buf_[i], src + off, len);
+    HIPCHK(hipMemcpyAsync(dst + off, h2d_buf_[i], len, hipMemcpyHostToDevice, stream_), "val H2D");
+    HIPCHK(hipEventRecord(h2d_ev_[i], stream_), "event");
+    h2d_busy_[i] = true;
+  }
+  return 0;
+}
+
+int Engine::sync_stream(hipStream_t st, const char* what) {
+  const double limit_s = hip_deadline_s();
   if (limit_s <= 0) {
     hipError_t e = hipStreamSynchronize(st);
     return e == hipSuccess ? 0 : fail(kErrHip, what, e);
@@ -114,17 +279,49 @@ int Engine::sync_stream(hipStream_t st, const char* what) {
     if (streams_[i]) rep += " stream " + std::to_string(i) + (hipStreamQuery(streams_[i]) == hipSuccess ? " idle;" : " busy;");
   status_ = kErrHip;
   err_ = rep;
+  // The device may still be working on (or stuck in) what this engine enqueued: nothing of it is
+  // touched again -- no further synchronisation (it would block for good), and its streams,
+  // events, pinned words and device buffers are neither reused nor freed (see ~Engine).
+  poisoned_ = true;
   std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
   return kErrHip;
 }
 
+hipError_t Engine::dalloc(void** p, size_t bytes) {
+  hipError_t e = dev_alloc(p, bytes, device_);
+  if (e == hipSuccess) owned_.push_back({*p, std::max<size_t>(bytes, 256)});
+  return e;
+}
+
 template <class Tp>
-static hipError_t dev_upload(Tp** dptr, const std::vector<Tp>& v) {
+hipError_t Engine::dev_upload(Tp** dptr, const std::vector<Tp>& v) {
   size_t bytes = sizeof(Tp) * (v.empty() ? 1 : v.size());
-  hipError_t e = hipMalloc((void**)dptr, bytes);
+  hipError_t e = dalloc((void**)dptr, bytes);
   if (e != hipSuccess) return e;
   if (!v.empty()) e = hipMemcpy(*dptr, v.data(), sizeof(Tp) * v.size(), hipMemcpyHostToDevice);
   return e;
+}
+
+// EngineOptions -> ScheduleOptions, in ONE place (the engine and the host-only program of
+// spllt_hip_program_get / the CPU tests must build the same program); resolves the "-1 = decide by
+// the problem" options of opt in place.
+ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
+  ScheduleOptions so;
+  so.pw = opt.pw;
+  so.tile = opt.tile;
+  so.cb = opt.cb;
+  so.lookahead = opt.lookahead;
+  so.slice_between = opt.slice_between;
+  so.deterministic = opt.deterministic;
+  so.fused_panel = opt.fused_panel;
+  const bool lb = latency_bound(S, std::min(opt.pw, kPanelMax));
+  if (opt.reserve_cus < 0) opt.reserve_cus = lb ? 32 : 0;
+  if (opt.zones < 0) opt.zones = lb ? 1 : 0;
+  so.zones = opt.zones != 0;
+  // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
+  // large configurations; the latency-bound bench workload prefers 4096 (24.5 vs 25.0 ms)
+  so.tile128_min = lb ? 4096 : 1024;
+  return so;
 }
 
 void partition_options(const Symbolic& S, const EngineOptions& opt, std::vector<int>& owner,
@@ -158,23 +355,7 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
     return;
   }
   hipGetDevice(&device_);
-  ScheduleOptions so;
-  so.pw = opt_.pw;
-  so.tile = opt_.tile;
-  so.cb = opt_.cb;
-  so.lookahead = opt_.lookahead;
-  so.slice_between = opt_.slice_between;
-  so.deterministic = opt_.deterministic;
-  so.fused_panel = opt_.fused_panel;
-  {
-    const bool lb = latency_bound(*S_, std::min(opt_.pw, kPanelMax));
-    if (opt_.reserve_cus < 0) opt_.reserve_cus = lb ? 32 : 0;
-    if (opt_.zones < 0) opt_.zones = lb ? 1 : 0;
-    so.zones = opt_.zones != 0;
-    // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
-    // large configurations; the latency-bound bench workload prefers 4096 (24.5 vs 25.0 ms)
-    so.tile128_min = lb ? 4096 : 1024;
-  }
+  ScheduleOptions so = schedule_options(*S_, opt_);
   if (opt_.nranks > 1) {
     partition_options(*S_, opt_, owner_, top_owner_, so);
     for (int b = 0; b < S_->nbcol(); ++b)
@@ -194,13 +375,16 @@ Engine::Engine(std::shared_ptr<const Symbolic> S, const EngineOptions& opt)
   build_program(*S_, so, prog_);
   arena_elems_ = S_->arena;
   if (opt_.nranks > 1) localize_program();
-  upload();
+  if (status_ == 0) upload();
 }
 
 // Breadcrumbs (SPLLT_HIP_CRUMBS=<file>): the last step the library reached, rewritten at every
 // step.  After a call that never returned (a wedged runtime call cannot be interrupted or traced
 // from the caller) the file names the step.
+static std::atomic<const char*> g_last_crumb{"(nothing yet)"};
+const char* last_crumb() { return g_last_crumb.load(); }
 static void crumb(const char* what) {
+  g_last_crumb.store(what);
   static const char* path = std::getenv("SPLLT_HIP_CRUMBS");
   if (!path || !*path) return;
   if (FILE* f = std::fopen(path, "w")) {
@@ -291,6 +475,56 @@ static void return_streams(hipStream_t chain) {
     if (ss.chain == chain) ss.in_use = false;
 }
 
+namespace {
+// atexit: the pools go before the HIP runtime does (see the comment at the pools).  Streams that
+// are still in use (a leaked, poisoned engine) or not idle are left alone.
+void pools_teardown() {
+  // SPLLT_TEARDOWN: 0 nothing, 1 (default) everything but the streams, 2 the streams too.
+  // hipStreamDestroy of a CU-masked stream is the one call of this library that has been caught
+  // not returning (profiles/r03/hang_evidence.txt): it is not made unless asked for -- the
+  // profiling scripts ask, because rocprofv3's own teardown crashes on live CU-masked queues,
+  // and they run under a timeout.
+  static const int mode = [] { const char* e = std::getenv("SPLLT_TEARDOWN"); return e ? std::atoi(e) : 1; }();
+  if (mode == 0) return;
+  crumb("teardown: streams (lock)");
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  for (StreamSet& ss : g_stream_pool) {
+    if (mode < 2) break;
+    if (ss.in_use) continue;
+    crumb("teardown: streams (query)");
+    if (hipStreamQuery(ss.chain) != hipSuccess || hipStreamQuery(ss.bulk) != hipSuccess ||
+        hipStreamQuery(ss.far) != hipSuccess) continue;
+    crumb("teardown: streams (destroy chain)");
+    (void)hipStreamDestroy(ss.chain);
+    crumb("teardown: streams (destroy bulk)");
+    (void)hipStreamDestroy(ss.bulk);
+    crumb("teardown: streams (destroy far)");
+    if (ss.far != ss.bulk) (void)hipStreamDestroy(ss.far);
+    ss.chain = ss.bulk = ss.far = nullptr;
+    ss.in_use = true;        // (never handed out again)
+  }
+  crumb("teardown: events");
+  for (auto& pool : g_event_pool) {
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+  crumb("teardown: pinned memory");
+  {
+    std::lock_guard<std::mutex> lk2(g_pinned_mu);
+    for (int* q : g_pinned_words) (void)hipHostFree(q);
+    g_pinned_words.clear();
+  }
+  std::lock_guard<std::mutex> lk3(g_pool_mu);
+  for (const PinBuf& b : g_pin_cache) (void)hipHostFree(b.p);
+  g_pin_cache.clear();
+  crumb("teardown: device buffers");
+  for (const DevBuf& b : g_dev_cache) (void)hipFree(b.p);
+  g_dev_cache.clear();
+  g_dev_cached_bytes = 0;
+  crumb("teardown: done");
+}
+}  // namespace
+
 int Engine::upload() {
   const Symbolic& S = *S_;
   crumb("engine: upload begins");
@@ -331,9 +565,9 @@ int Engine::upload() {
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
   // (+ 32 doubles: the update kernel loads whole 16-column chunks, the last one of a ragged K
   // window reaches past the block column's end)
-  HIPCHK(hipMalloc((void**)&d_L_, sizeof(double) * (size_t)(std::max<int64_t>(1, arena_elems_) + 32)), "hipMalloc(L arena)");
-  HIPCHK(hipMalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
-  HIPCHK(hipMalloc((void**)&d_dinv_, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMalloc(dinv)");
+  HIPCHK(dalloc((void**)&d_L_, sizeof(double) * (size_t)(std::max<int64_t>(1, arena_elems_) + 32)), "hipMalloc(L arena)");
+  HIPCHK(dalloc((void**)&d_val_, sizeof(double) * (size_t)std::max<int64_t>(1, S.nnzA)), "hipMalloc(val)");
+  HIPCHK(dalloc((void**)&d_dinv_, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMalloc(dinv)");
   // the POTRF kernels store the lower triangle of an inverted panel only; what lies above the
   // diagonal of a slot is zero from here on (nothing else writes there)
   HIPCHK(hipMemset(d_dinv_, 0, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMemset(dinv)");
@@ -372,7 +606,7 @@ int Engine::upload() {
   tab.add(&d_bc_w_, w);
   std::vector<UpdUnit> units;    // (outlives the staging copy below)
   if (prog_.scratch_size > 0) {
-    HIPCHK(hipMalloc((void**)&d_scratch_, sizeof(double) * (size_t)prog_.scratch_size), "hipMalloc(scratch)");
+    HIPCHK(dalloc((void**)&d_scratch_, sizeof(double) * (size_t)prog_.scratch_size), "hipMalloc(scratch)");
     // MODE_BUFFER units address the scratch relative to the arena pointer like every other unit
     units = prog_.units;
     const int64_t shift = d_scratch_ - d_L_;
@@ -393,7 +627,7 @@ int Engine::upload() {
   tab.add(&d_rlist_, S.rlist);
   const int big_flag = INT_MAX;
   tab.add(&d_flag_, &big_flag, 1);
-  HIPCHK(tab.commit(&d_tables_), "upload tables");
+  HIPCHK(tab.commit(&d_tables_, [this](void** q, size_t b) { return dalloc(q, b); }), "upload tables");
   HIPCHK(borrow_pinned_word(&h_flag_), "hipHostMalloc(flag)");
   crumb("engine: ready");
   return 0;
@@ -409,8 +643,10 @@ int64_t Engine::to_local(int64_t g) const {
     if (bc[mid].off <= g) lo = mid; else hi = mid;
   }
   if (bc[lo].off != g || loc_off_[lo] < 0) {
+    // (const: called from a const context too; the flag is picked up by localize_program)
     std::fprintf(stderr, "spllt-hip: internal error: arena offset %lld is not a block column held by rank %d\n",
                  (long long)g, opt_.rank);
+    localize_failed_ = true;
     return 0;
   }
   return loc_off_[lo];
@@ -437,21 +673,39 @@ void Engine::localize_program() {
   for (GatherTile& t : prog_.gather_tiles) t.d_off = to_local(t.d_off);
   for (ExchangeItem& it : prog_.xitems)
     if (it.space == 0) it.off = to_local(it.off);
+  if (localize_failed_) {
+    // a table entry points at a block column this rank does not hold: running the program would
+    // silently read and write this rank's first block column instead
+    status_ = -30;
+    err_ = "internal error: the rank's program refers to a block column it does not hold";
+  }
 }
 
 Engine::~Engine() {
+  if (graph_exec_ && !poisoned_) hipGraphExecDestroy(graph_exec_);
+  if (graph_ && !poisoned_) hipGraphDestroy(graph_);
+  if (poisoned_) {
+    // A wait of this engine ran into its deadline (or its submission never returned): the device
+    // may still execute, or be stuck in, what it enqueued.  Nothing is synchronised (that would
+    // block for good), nothing goes back into the pools (the next engine would run behind, or
+    // beside, the stale program), nothing the queued work may touch is freed: it is leaked.
+    crumb("engine: poisoned, resources leaked");
+    return;
+  }
   crumb("engine: destructor, draining streams");
   for (hipStream_t st : streams_)
-    if (st) hipStreamSynchronize(st);
-  if (graph_exec_) hipGraphExecDestroy(graph_exec_);
-  if (graph_) hipGraphDestroy(graph_);
-  crumb("engine: destructor, freeing");
+    if (st && sync_stream(st, "engine teardown") != 0) {
+      crumb("engine: teardown ran into the deadline, resources leaked");
+      return;                               // (poisoned by sync_stream)
+    }
+  crumb("engine: destructor, releasing");
   return_events(dag_events_, device_);       // (the streams are drained: nothing refers to them any more)
-  hipFree(d_L_); hipFree(d_val_); hipFree(d_dinv_); hipFree(d_map_dst_); hipFree(d_map_src_);
-  hipFree(d_scratch_);
-  hipFree(d_tables_);         // bc_off, bc_w, units, tiles, chain / panel units, counters, gather tables, relpos, rlist, flag
-  hipFree(d_solve_tables_);   // solve units, list, tiles
-  hipFree(d_y_);
+  for (const auto& b : owned_) dev_release(b.first, b.second, device_);   // kept for the next engine, not hipFree'd:
+  owned_.clear();                                                          // hipFree synchronises the whole device
+  if (h2d_buf_[0]) pin_release(h2d_buf_[0], h2d_chunk_);
+  if (h2d_buf_[1]) pin_release(h2d_buf_[1], h2d_chunk_);
+  for (hipEvent_t e : h2d_ev_)
+    if (e) hipEventDestroy(e);
   return_pinned_word(h_flag_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
@@ -751,7 +1005,15 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipEventRecord(ev0_, stream_), "event");
   crumb("factor: H2D of val");
-  HIPCHK(hipMemcpyAsync(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream_), "val H2D");
+  // test hook (tests/test_gpu_parity.py::test_submission_deadline): a runtime call that sits
+  if (const char* e = std::getenv("SPLLT_HIP_TEST_STALL_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(e)));
+  static const bool direct_h2d = [] { const char* e = std::getenv("SPLLT_HIP_H2D"); return e && std::string(e) == "direct"; }();
+  if (direct_h2d) {
+    HIPCHK(hipMemcpyAsync(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream_), "val H2D");
+  } else {
+    int rc = stage_val(val_host, nnz);
+    if (rc) return rc;
+  }
   HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
   crumb("factor: enqueueing the program");
   int rc = enqueue_program();
@@ -818,9 +1080,9 @@ int Engine::prepare_solve() {
     tab.add(&d_sunits_, sprog_.units);
     tab.add(&d_slist_, sprog_.diag_list);
     tab.add(&d_stiles_, sprog_.tiles);
-    HIPCHK(tab.commit(&d_solve_tables_), "upload solve tables");
+    HIPCHK(tab.commit(&d_solve_tables_, [this](void** q, size_t b) { return dalloc(q, b); }), "upload solve tables");
   }
-  HIPCHK(hipMalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
+  HIPCHK(dalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
   solve_ready_ = true;
   return 0;
 }
@@ -930,6 +1192,94 @@ int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<fl
   for (size_t i = 0; i < nl; ++i) hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]);
   for (auto& e : ev) hipEventDestroy(e);
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Submission under a deadline.  Everything spllt_factor does before it returns -- engine
+// creation (stream / event borrowing, allocations, synchronous table upload), the staging of
+// val, ~650 launches -- is a sequence of runtime calls that normally take microseconds but that
+// nobody can interrupt once one of them sits in the driver (the one hang of round 2 that was not
+// in a wait sat here).  They run on ONE helper thread per process; the caller waits for the job
+// with the deadline of the other waits.  A job that does not come back marks the runtime as
+// wedged: that call and every later one fail with SPLLT_ERROR_HIP and the name of the last step
+// reached, instead of blocking the caller forever.  (SPLLT_HIP_TIMEOUT_S=0: no helper thread,
+// the calls run inline.)
+// ---------------------------------------------------------------------------
+namespace {
+struct SubmitJob {
+  std::function<int()> fn;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = 0;
+};
+struct SubmitWorker {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<SubmitJob>> queue;
+  std::atomic<bool> wedged{false};
+  SubmitWorker() {
+    std::thread([this] {
+      for (;;) {
+        std::shared_ptr<SubmitJob> job;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [this] { return !queue.empty(); });
+          job = queue.front();
+          queue.pop_front();
+        }
+        const int rc = job->fn();
+        {
+          std::lock_guard<std::mutex> lk(job->mu);
+          job->rc = rc;
+          job->done = true;
+        }
+        job->cv.notify_all();
+      }
+    }).detach();
+  }
+};
+SubmitWorker& submit_worker() {
+  static SubmitWorker* w = new SubmitWorker();   // never destroyed: its thread outlives main()
+  return *w;
+}
+}  // namespace
+
+int run_with_deadline(std::function<int()> fn, std::string* why) {
+  // (SPLLT_HIP_SUBMIT_TIMEOUT_S: a deadline of its own -- a wait may legitimately be given a few
+  // milliseconds by a caller that polls, engine creation may not)
+  static const double limit_s = [] {
+    const char* e = std::getenv("SPLLT_HIP_SUBMIT_TIMEOUT_S");
+    if (e && *e) return std::atof(e);
+    return hip_deadline_s() <= 0 ? 0.0 : 180.0;
+  }();
+  static const bool inline_env = std::getenv("SPLLT_HIP_SUBMIT_INLINE") != nullptr;
+  if (limit_s <= 0 || inline_env) return fn();
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return fn();     // (no device: the engine reports that itself)
+  SubmitWorker& w = submit_worker();
+  if (w.wedged.load()) {
+    if (why) *why = std::string("the HIP runtime did not return from an earlier call (") + last_crumb() + ")";
+    return kErrHip;
+  }
+  auto job = std::make_shared<SubmitJob>();
+  job->fn = [fn, dev]() -> int {
+    (void)hipSetDevice(dev);                             // the caller's device, not the helper thread's default
+    return fn();
+  };
+  {
+    std::lock_guard<std::mutex> lk(w.mu);
+    w.queue.push_back(job);
+  }
+  w.cv.notify_one();
+  std::unique_lock<std::mutex> lk(job->mu);
+  if (job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) return job->rc;
+  w.wedged.store(true);
+  if (why)
+    *why = std::string("submission did not return within ") + std::to_string((int)limit_s) + " s; last step: " +
+           last_crumb();
+  std::fprintf(stderr, "spllt-hip: %s\n", why ? why->c_str() : "submission deadline");
+  return kErrHip;
 }
 
 }  // namespace spx

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -14,6 +15,14 @@
 #include "symbolic.hpp"
 
 namespace spx {
+
+// deadline of every blocking wait, seconds (SPLLT_HIP_TIMEOUT_S, default 180; 0: none)
+double hip_deadline_s();
+// runs fn on the process's submission thread and waits for it with that deadline; a job that
+// does not come back makes this call and every later one return SPLLT_ERROR_HIP (-30) with *why
+// naming the last step the library reached (engine.cpp)
+int run_with_deadline(std::function<int()> fn, std::string* why);
+const char* last_crumb();
 
 struct EngineOptions {
   int pw = 64;
@@ -42,6 +51,9 @@ struct FactorStats {
   int launches = 0;
 };
 
+// EngineOptions -> ScheduleOptions (the one place); resolves the "decide by the problem" options of opt
+ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt);
+
 // Partition of the tree for opt.nranks ranks: node owners, and (distributed top tree) the owners of
 // the top-tree block columns; fills the partition fields of so (the vectors must outlive it).
 void partition_options(const Symbolic& S, const EngineOptions& opt, std::vector<int>& owner,
@@ -55,6 +67,8 @@ class Engine {
   Engine& operator=(const Engine&) = delete;
 
   int status() const { return status_; }  // 0 or SPLLT error flag from construction
+  bool poisoned() const { return poisoned_; }
+  void poison(const std::string& why) { poisoned_ = true; status_ = -30; err_ = why; }
   const std::string& error() const { return err_; }
 
   // spllt_factor: enqueue H2D of val, value scatter and the whole program.
@@ -132,6 +146,22 @@ class Engine {
   int bulk_pad128_ = 0, bulk_pad64_ = 0;
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
+  // device buffers of this engine (pointer, bytes): taken from / returned to the process-wide cache
+  std::vector<std::pair<void*, size_t>> owned_;
+  hipError_t dalloc(void** p, size_t bytes);
+  template <class Tp> hipError_t dev_upload(Tp** dptr, const std::vector<Tp>& v);
+  // host-to-device copy of val through two pinned staging buffers (spllt_factor's val is pageable
+  // user memory: handing it to hipMemcpyAsync makes the "asynchronous" copy a blocking one inside
+  // the runtime, which pins or stages it there)
+  static constexpr size_t kH2dChunk = (size_t)16 << 20, kH2dSmall = (size_t)256 << 10;
+  size_t h2d_chunk_ = 0;
+  void* h2d_buf_[2] = {nullptr, nullptr};
+  hipEvent_t h2d_ev_[2] = {nullptr, nullptr};
+  bool h2d_busy_[2] = {false, false};
+  int stage_val(const double* val_host, int64_t nnz);
+  int wait_event(hipEvent_t ev, const char* what);
+  bool poisoned_ = false;   // a wait ran into its deadline: see ~Engine
+  mutable bool localize_failed_ = false;
   int graph_mode_ = 0;
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;

@@ -125,7 +125,32 @@ struct Builder {
       std::stable_sort(t64.begin(), t64.end(), by_work);
       std::stable_sort(t32.begin(), t32.end(), by_work);
     }
-    double ntot = (double)t128.size() * 16 + (double)t64.size() * 4 + (double)t32.size();
+    // useful flops of ONE tile of a unit, the convention of the whole program (and of the
+    // reference's symbolic count): 2 K per entry the tile really computes for the destination
+    // (entries above the diagonal of a unit that straddles it do not count); TRSM: the
+    // triangular solve (N per entry) + the left-looking part folded into it (2 (K - N))
+    const int ubase0 = (int)P.units.size() - (int)us.size();
+    auto tile_flops = [&](const UpdTile& t, int T) {
+      const UpdUnit& u = us[(size_t)(t.unit - ubase0)];
+      const int i0 = t.ti * T, i1 = std::min(u.M, i0 + T), j0 = t.tj * T, j1 = std::min(u.N, j0 + T);
+      if (i1 <= i0 || j1 <= j0) return 0.0;
+      int64_t k = 0;
+      if (u.nseg == 1) k = u.klen >= 0 ? u.klen : S.bcols[u.src_bcol0].width;
+      else for (int sg = 0; sg < u.nseg; ++sg) k += S.bcols[u.src_bcol0 + sg].width;
+      if (u.mode == MODE_TRSM) return (double)(i1 - i0) * (j1 - j0) * ((double)u.N + 2.0 * (double)(k - u.N));
+      double cnt = 0;
+      // (the reporting convention of direct_flops: a DIRECT unit is cut at the diagonal only when
+      // it starts on it; inter-node units always are)
+      const bool cut = lower && u.lower && (u.mode != MODE_DIRECT || u.src_r0 == u.src_c0);
+      if (!cut) cnt = (double)(i1 - i0) * (j1 - j0);
+      else
+        for (int j = j0; j < j1; ++j) {
+          const int lo = std::max(i0, u.src_c0 + j - u.src_r0);   // first row with src_r0 + i >= src_c0 + j
+          if (lo < i1) cnt += i1 - lo;
+        }
+      return 2.0 * (double)k * cnt;
+    };
+    (void)flops;
     std::vector<UpdTile>* lists[3] = {&t128, &t64, &t32};
     const int edges[3] = {128, 64, 32};
     int first_nonempty = -1, last_nonempty = -1;
@@ -143,7 +168,8 @@ struct Builder {
       L.first = (int64_t)P.tiles.size();
       L.count = (int64_t)tv.size();
       L.tile = edges[pass];
-      L.flops = flops * ((double)tv.size() * (edges[pass] / 32) * (edges[pass] / 32)) / std::max(1.0, ntot);
+      L.flops = 0;
+      for (const UpdTile& t : tv) L.flops += tile_flops(t, edges[pass]);
       L.stream = e.stream;
       if (pass == first_nonempty) {
         L.add_wait(e.wait0);

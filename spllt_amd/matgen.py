@@ -152,6 +152,41 @@ def read_mtx(path):
     return A
 
 
+def invent_values(count, seed=1):
+    """Values for a pattern-only file (the reference makes them up with SPRAL's random_real,
+    src/spllt_mod.F90:480-485): uniform in (-1, 1) from splitmix64 -- the stream the library's
+    readers use (spllt_amd/csrc/readers.cpp), so that both give the same matrix."""
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, count + 1, dtype=np.uint64)
+        z = (s ^ (s >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(11)).astype(np.float64) + 0.5) * (2.0 / 9007199254740992.0) - 1.0
+
+
+def read_file_c(path, kind=None, values=3, seed=1):
+    """A matrix file through the LIBRARY's readers (spllt_hip_read_rb / spllt_hip_read_mm, the
+    C boundary): returns (n, ptr, row, val) of the lower triangle, 1-based CSC, as numpy arrays."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if kind is None:
+        kind = "mm" if str(path).endswith((".mtx", ".mm")) else "rb"
+    n, nnz = C.c_int(), C.c_int()
+    ptr, row, val = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    fn = lib.spllt_hip_read_mm if kind == "mm" else lib.spllt_hip_read_rb
+    rc = fn(str(path).encode(), values, seed, C.byref(n), C.byref(nnz), C.byref(ptr), C.byref(row), C.byref(val))
+    if rc != 0:
+        raise ValueError(f"{path}: reader failed with flag {rc}")
+    try:
+        p = np.ctypeslib.as_array(ptr, shape=(n.value + 1,)).copy()
+        r = np.ctypeslib.as_array(row, shape=(max(nnz.value, 1),))[:nnz.value].copy()
+        v = np.ctypeslib.as_array(val, shape=(max(nnz.value, 1),))[:nnz.value].copy()
+    finally:
+        lib.spllt_hip_free_matrix(ptr, row, val)
+    return n.value, p, r, v
+
+
 def _fortran_fields(fmt):
     """(count, width) of a Rutherford-Boeing Fortran format such as (10I8),
     (1P,3E25.16), (4D20.12) or (8F10.3): fields are fixed-width and may abut"""
@@ -184,7 +219,7 @@ def read_rb(path, values=3, seed=1):
     rb_read).  `values` follows the driver's use of rb_options%values:
       0  values as in the file (a pattern-only file is an error),
       3  what every reference driver asks for ("force diagonal dominance"): keep the
-         file's off-diagonal values, or invent them (uniform in (-1, 1), fixed seed --
+         file's off-diagonal values, or invent them (uniform in (-1, 1), invent_values --
          the reference uses SPRAL's random_real for missing values,
          src/spllt_mod.F90:480-485) when the file holds a pattern only, then set every
          diagonal entry to 1 + sum |off-diagonal entries of its row| so that the matrix
@@ -217,7 +252,7 @@ def read_rb(path, values=3, seed=1):
     elif values == 0:
         raise ValueError("pattern-only file and values=0")
     else:
-        val = np.random.default_rng(seed).uniform(-1.0, 1.0, size=nnz)
+        val = invent_values(nnz, seed)
     if ptr[0] != 0 or ptr[-1] != nnz or (np.diff(ptr) < 0).any() or ind.min() < 0 or ind.max() >= nrow:
         raise ValueError("inconsistent column pointers / row indices")
     L = sp.csc_matrix((val, ind, ptr), shape=(nrow, ncol))

@@ -111,3 +111,74 @@ def drive_exchanges(fs, bufs, on_exchange=None):
         for f in fs:
             f.continue_after_exchange()
         nx += 1
+
+
+# ---- foreign symbolic factorizations for spllt_hip_analyse_symbolic ----------
+def quintuple_single_columns(f):
+    """every column its own supernode: the finest partition of f's elimination tree
+    (sptr, sparent, rptr, rlist, order as SSIDS would deliver them, 0-based)"""
+    n = f.n
+    sptr, sparent, rptr, rlist, order = (f.sym(k) for k in ("sptr", "sparent", "rptr", "rlist", "order"))
+    nsptr, nspar, nrptr, nrl = [0], [], [0], []
+    for s in range(len(sparent)):
+        rows = rlist[rptr[s]:rptr[s + 1]]
+        nc = sptr[s + 1] - sptr[s]
+        for k in range(nc):
+            j = sptr[s] + k
+            nsptr.append(j + 1)
+            nrl.extend(rows[k:].tolist())
+            nrptr.append(len(nrl))
+            if k + 1 < nc:
+                nspar.append(j + 1)
+            else:
+                p = sparent[s]
+                nspar.append(int(sptr[p]) if p < len(sparent) else n)
+    return dict(sptr=np.array(nsptr), sparent=np.array(nspar), rptr=np.array(nrptr), rlist=np.array(nrl),
+                order=order)
+
+
+def quintuple_hand_amalgamated(f, every=2):
+    """a coarser partition than f's: a node is merged into its parent where the parent follows it
+    directly in the postorder and has no other child (columns stay contiguous; the merged row list
+    = the two column sets, then the sorted union of the rows below -- explicit zeros where the
+    child had fewer rows).  Every `every`-th eligible pair is merged, bottom-up."""
+    sptr, sparent, rptr, rlist, order = (np.asarray(f.sym(k)) for k in ("sptr", "sparent", "rptr", "rlist", "order"))
+    nn = len(sparent)
+    nchild = np.zeros(nn + 1, dtype=int)
+    for s in range(nn):
+        nchild[min(sparent[s], nn)] += 1
+    nodes = [dict(c0=int(sptr[s]), c1=int(sptr[s + 1]), rows=list(map(int, rlist[rptr[s]:rptr[s + 1]])),
+                  parent=int(sparent[s]), alive=True) for s in range(nn)]
+    k = 0
+    for s in range(nn - 1):
+        p = nodes[s]["parent"]
+        if p != s + 1 or p >= nn or nchild[p] != 1:
+            continue
+        k += 1
+        if k % every:
+            continue
+        a, b = nodes[s], nodes[p]
+        below = sorted((set(a["rows"][a["c1"] - a["c0"]:]) | set(b["rows"][b["c1"] - b["c0"]:])) - set(range(b["c0"], b["c1"])))
+        b["rows"] = list(range(a["c0"], b["c1"])) + below
+        b["c0"] = a["c0"]
+        a["alive"] = False
+        nchild[p] = nchild[s]             # the merged node inherits the child's children
+    newid = {}
+    for s in range(nn):
+        if nodes[s]["alive"]:
+            newid[s] = len(newid)
+    def target(s):                        # a dead node lives on in its parent
+        while s < nn and not nodes[s]["alive"]:
+            s = nodes[s]["parent"]
+        return s
+    nsptr, nspar, nrptr, nrl = [0], [], [0], []
+    for s in range(nn):
+        if not nodes[s]["alive"]:
+            continue
+        nsptr.append(nodes[s]["c1"])
+        nrl.extend(nodes[s]["rows"])
+        nrptr.append(len(nrl))
+        p = target(nodes[s]["parent"]) if nodes[s]["parent"] < nn else nn
+        nspar.append(newid[p] if p < nn else len(newid))
+    return dict(sptr=np.array(nsptr), sparent=np.array(nspar), rptr=np.array(nrptr), rlist=np.array(nrl),
+                order=order)

@@ -132,6 +132,45 @@ def test_refactorize_same_pattern_and_device_val():
     f.factor_dev(dval.data_ptr()).wait()
     L2 = f.get_factor()
     np.testing.assert_allclose(L2, L1 * np.sqrt(2.0), rtol=1e-13, atol=1e-14)
+    # ... and each of the two against the oracle's factorization of the same values
+    mask = lower_mask(f)
+    for got, v in ((L1, val), (L2, val * 2.0)):
+        o, rc = oracle_factor(f, v)
+        assert rc == 0
+        assert rel_err(got, o.arena(), mask) <= TOL_L
+
+
+def test_init_lfact_twin():
+    """spllt_init_lfact_hip, the stream-taking twin of spllt_init_node_c / spllt_init_blk_c
+    (reference kernels_mod:2301-2364, :2392-2423: lcol(map(1,i)) = val(map(2,i)) on a zeroed
+    lcol) for the whole arena, against the oracle's own lmap (re-derived from the symbolic
+    structure by the oracle, oracle/spllt_oracle.c): bit-exact."""
+    torch = _torch()
+    from oracle import pyoracle
+    from spllt_amd import _lib
+    A = matgen.nd_like((8, 8, 7), 2)
+    f, val = make_case(A, nb=48, nemin=8)
+    val = val * (1.0 + 0.001 * np.arange(val.size))            # every entry different
+    o = pyoracle.OracleFactor.from_factorization(f)
+    bc_off = np.asarray(f.sym("bcol_off"))
+    arena = int(f.sym_info()["arena"])
+    exp = np.zeros(arena)
+    for b in range(bc_off.size):
+        k = int(o.lib.spo_lmap_len(o.h, b))
+        if k == 0:
+            continue
+        dst = np.ctypeslib.as_array(o.lib.spo_lmap_dst(o.h, b), shape=(k,))
+        src = np.ctypeslib.as_array(o.lib.spo_lmap_src(o.h, b), shape=(k,))
+        exp[bc_off[b] + dst] = val[src]
+    assert np.count_nonzero(exp) == val.size
+    dL = torch.zeros(arena, dtype=torch.float64, device="cuda")
+    dv = _dev(torch, val)
+    dd, ds = _dev(torch, np.asarray(f.sym("map_dst"), dtype=np.int64)), _dev(torch, np.asarray(f.sym("map_src"), dtype=np.int64))
+    torch.cuda.synchronize()
+    rc = _lib.load().spllt_init_lfact_hip(None, dL.data_ptr(), dv.data_ptr(), dd.data_ptr(), ds.data_ptr(), val.size)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(dL.cpu().numpy(), exp)
 
 
 def test_not_positive_definite_is_reported():
@@ -151,6 +190,8 @@ def test_linearity_of_scaling():
     L1 = f.factor(val).wait().get_factor()
     L2 = f.factor(val * 4.0).wait().get_factor()
     np.testing.assert_allclose(L2, 2.0 * L1, rtol=1e-13, atol=1e-14)
+    o, rc = oracle_factor(f, val * 4.0)      # (and not only with itself)
+    assert rc == 0 and rel_err(L2, o.arena(), lower_mask(f)) <= TOL_L
 
 
 # ---- per-kernel operator twins against the oracle's kernels -----------------
@@ -720,6 +761,7 @@ def test_sync_watchdog_reports_where_the_program_stands():
         "    print('FINISHED')\n"
         "except api.SplltError as e:\n"
         "    print('FLAG', e.flag); print(str(e))\n"
+        "import time; t0 = time.time(); f.close(); print('CLOSED in %%.2f s' %% (time.time() - t0))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, SPLLT_HIP_TIMEOUT_S="0.0000001"))
@@ -729,6 +771,93 @@ def test_sync_watchdog_reports_where_the_program_stands():
     # (the launches that have not finished are listed -- unless the device got through the small
     # factorization between the missed deadline and the report, which then says the streams are idle)
     assert "has not finished" in out or "stream 0 idle" in out, out
+    # the handle whose wait ran into the deadline closes at once: its engine is poisoned, nothing
+    # of it is synchronised, returned to the pools or freed (an unbounded hipStreamSynchronize in
+    # the destructor would sit on a device that is really stuck)
+    assert "CLOSED in" in out and r.returncode == 0, out
+
+
+@pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson3d(40), 384), (lambda: matgen.nd_like((12, 11, 10), 2), 160)])
+def test_host_program_equals_engine_program(gen, nb):
+    """The host-only program (spllt_hip_program_get before the first factorization: what the CPU
+    DAG-conflict test, the numpy emulator and the partition model look at) and the program the
+    engine runs come from ONE options mapping (engine.cpp schedule_options), incl. the decisions
+    taken from the problem (latency-bound or throughput-bound: zones, tile thresholds)."""
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=32)
+    before = {k: np.array(f.program(k)) for k in ("launches", "tiles", "units")}
+    f.factor(val).wait()
+    for k, v in before.items():
+        after = np.array(f.program(k))
+        assert after.shape == v.shape and np.array_equal(after, v), k
+    f.close()
+
+
+@pytest.mark.parametrize("kind", ["single-columns", "hand-amalgamated"])
+@pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson2d(20), 8), (lambda: matgen.nd_like((9, 8, 8), 2), 64),
+                                    (lambda: matgen.fe27((6, 5, 5), 3), 96)])
+def test_foreign_symbolic_factorization_on_the_gpu(kind, gen, nb):
+    """spllt_hip_analyse_symbolic takes the symbolic factorization the reference
+    gets from SSIDS (src/spllt_analyse_mod.F90:129-158) -- here two partitions the product's own
+    analyse would never produce: every column its own node, and a hand-amalgamated coarser one
+    -- and spllt_factor runs on exactly that tree: the HIP path against the oracle on the same
+    (foreign) symbolic structure."""
+    from helpers import quintuple_hand_amalgamated, quintuple_single_columns
+    A = gen()
+    base, val = make_case(A, nb=nb, nemin=1)
+    quint = quintuple_single_columns(base) if kind == "single-columns" else quintuple_hand_amalgamated(base)
+    n, ptr, row, _ = api.csc_lower_1based(A)
+    g = api.Factorization(n, ptr, row, nb=nb, nemin=32, symbolic=quint)
+    assert g.sym_info()["ordering"] == "symbolic"
+    if kind == "single-columns":
+        assert g.sym_info()["nnodes"] == n
+    else:
+        assert g.sym_info()["nnodes"] < base.sym_info()["nnodes"]
+    got = g.factor(val).wait().get_factor()
+    o, rc = oracle_factor(g, val)
+    assert rc == 0
+    assert rel_err(got, o.arena(), lower_mask(g)) <= TOL_L
+    b = A @ np.ones(n)
+    assert bwd_err(A, g.solve(b), b) <= 1e-14
+    g.close()
+    base.close()
+
+
+def test_submission_deadline():
+    """spllt_factor itself is under a deadline: engine creation, the staging of val and the
+    launches run on the library's helper thread; a runtime call that does not come back (simulated:
+    SPLLT_HIP_TEST_STALL_MS) makes spllt_factor FAIL with flag -30 and the name of the step it
+    sat in, every later call of the process fail at once, and the handle close without touching
+    the engine that the stuck thread still holds."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from spllt_amd import api, matgen\n"
+        "from helpers import make_case\n"
+        "f, val = make_case(matgen.poisson2d(24), nb=32, nemin=8)\n"
+        "g, val2 = make_case(matgen.poisson2d(16), nb=32, nemin=8)\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    f.factor(val).wait(); print('FINISHED')\n"
+        "except api.SplltError as e:\n"
+        "    print('FLAG', e.flag, 'after %%.1f s' %% (time.time() - t0)); print(str(e))\n"
+        "try:\n"
+        "    g.factor(val2).wait(); print('SECOND FINISHED')\n"
+        "except api.SplltError as e:\n"
+        "    print('SECOND FLAG', e.flag); print(str(e))\n"
+        "f.close(); g.close(); print('CLOSED after %%.1f s' %% (time.time() - t0))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, SPLLT_HIP_SUBMIT_TIMEOUT_S="1", SPLLT_HIP_TEST_STALL_MS="6000"))
+    out = r.stdout + r.stderr
+    assert "FLAG -30" in out and "submission did not return within 1 s; last step: factor: H2D of val" in out, out
+    assert "SECOND FLAG -30" in out and "did not return from an earlier call" in out, out
+    assert "CLOSED after" in out, out
+    t_closed = float(out.split("CLOSED after")[1].split()[0])
+    assert t_closed < 4.0, out       # (nobody waited for the 6 s the stuck call takes)
 
 
 def test_bench_contract_one_gpu():
@@ -754,7 +883,7 @@ def test_bench_contract_one_gpu():
     assert d["unit"] == "GFLOP/s" and d["value"] > 0 and "workload" in d["config"]
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 78.6
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac_in_program"] <= 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac_alone"] <= 1
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     chk = d["detail"]["check"]

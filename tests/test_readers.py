@@ -62,3 +62,83 @@ def test_rb_abutting_fixed_width_fields(tmp_path):
         fh.write(" 2.000E+00-1.000E+00 2.000E+00-1.000E+00 2.000E+00\n")
     B = matgen.read_rb(str(path), values=0).toarray()
     np.testing.assert_array_equal(B, [[2, -1, 0], [-1, 2, -1], [0, -1, 2]])
+
+
+# ---- the library's readers (C boundary) against the Python ones ---------------------------
+def _lower_csc(A):
+    L = sp.tril(sp.csc_matrix(A), format="csc")
+    L.sort_indices()
+    return L.shape[0], L.indptr + 1, L.indices + 1, L.data
+
+
+@pytest.mark.parametrize("values", [0, 3])
+def test_c_reader_rb_matches_python(tmp_path, values):
+    """spllt_hip_read_rb (include/spllt_hip.h; what the reference takes from SPRAL's rb_read,
+    drivers/spllt_omp.F90:78-85) on the files this module writes: same pattern, same values."""
+    A = _sym(60, 11)
+    path = tmp_path / "a.rb"
+    matgen.write_rb(str(path), A)
+    n, ptr, row, val = matgen.read_file_c(str(path), "rb", values=values)
+    en, eptr, erow, eval_ = _lower_csc(matgen.read_rb(str(path), values=values))
+    assert n == en and np.array_equal(ptr, eptr) and np.array_equal(row, erow)
+    np.testing.assert_allclose(val, eval_, rtol=1e-15, atol=0)
+
+
+def test_c_reader_rb_pattern_only_and_abutting_fields(tmp_path):
+    A = _sym(30, 7)
+    path = tmp_path / "p.rb"
+    matgen.write_rb(str(path), A, pattern_only=True)
+    n, ptr, row, val = matgen.read_file_c(str(path), "rb", values=3, seed=5)
+    en, eptr, erow, eval_ = _lower_csc(matgen.read_rb(str(path), values=3, seed=5))
+    assert n == en and np.array_equal(ptr, eptr) and np.array_equal(row, erow)
+    np.testing.assert_allclose(val, eval_, rtol=1e-15, atol=0)      # the same made-up values
+    with pytest.raises(ValueError):
+        matgen.read_file_c(str(path), "rb", values=0)
+    path = tmp_path / "t.rb"
+    with open(path, "w") as fh:
+        fh.write(f"{'tiny':<72}{'K':<8}\n")
+        fh.write(f"{3:14d}{1:14d}{1:14d}{1:14d}\n")
+        fh.write(f"{'rsa':<14}{3:14d}{3:14d}{5:14d}{0:14d}\n")
+        fh.write(f"{'(4I2)':<16}{'(5I2)':<16}{'(5E10.3)':<20}\n")
+        fh.write(" 1 3 5 6\n")
+        fh.write(" 1 2 2 3 3\n")
+        fh.write(" 2.000E+00-1.000E+00 2.000E+00-1.000E+00 2.000E+00\n")
+    n, ptr, row, val = matgen.read_file_c(str(path), "rb", values=0)
+    assert n == 3 and list(ptr) == [1, 3, 5, 6] and list(row) == [1, 2, 2, 3, 3]
+    np.testing.assert_array_equal(val, [2, -1, 2, -1, 2])
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_c_reader_mm_matches_python(tmp_path, symmetric):
+    """spllt_hip_read_mm (reference src/spllt_mod.F90:426-491 mm_double_read + :543-620
+    coo_to_csc_double) against scipy's reader: a symmetric file, and a general one read as
+    (A + A^T) / 2; with and without the values = 3 conditioning."""
+    import scipy.io
+    A = _sym(50, 21)
+    if not symmetric:
+        A = (A + sp.random(50, 50, density=0.05, random_state=np.random.RandomState(4), format="csc")).tocsc()
+    path = tmp_path / "a.mtx"
+    scipy.io.mmwrite(str(path), sp.coo_matrix(A), symmetry="symmetric" if symmetric else "general", precision=17)
+    E = matgen.read_mtx(str(path))
+    n, ptr, row, val = matgen.read_file_c(str(path), "mm", values=0)
+    en, eptr, erow, eval_ = _lower_csc(E)
+    assert n == en and np.array_equal(ptr, eptr) and np.array_equal(row, erow)
+    np.testing.assert_allclose(val, eval_, rtol=1e-15, atol=1e-300)
+    n, ptr, row, val = matgen.read_file_c(str(path), "mm", values=3)
+    off = E - sp.diags(E.diagonal())
+    D = (off + sp.diags(1.0 + np.asarray(abs(off).sum(axis=1)).ravel())).tocsc()
+    en, eptr, erow, eval_ = _lower_csc(D)
+    assert np.array_equal(ptr, eptr) and np.array_equal(row, erow)
+    np.testing.assert_allclose(val, eval_, rtol=1e-14, atol=0)
+
+
+def test_c_reader_feeds_the_c_api(tmp_path):
+    """file -> spllt_hip_read_rb -> spllt_analyse, all at the C boundary (no GPU needed up to here)"""
+    from spllt_amd import api
+    A = _sym(80, 31)
+    path = tmp_path / "a.rb"
+    matgen.write_rb(str(path), A)
+    n, ptr, row, val = matgen.read_file_c(str(path), "rb", values=3)
+    f = api.Factorization(n, ptr.astype(np.int32), row.astype(np.int32), nb=16, nemin=4)
+    assert f.sym_info()["n"] == 80 and f.sym_info()["nnz_a"] == val.size
+    f.close()
