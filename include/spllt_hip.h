@@ -186,6 +186,18 @@ int spllt_hip_set_chain_block(void *fkeep, int chain_block);
  * the "not positive definite" indicator, at the very end.
  * exchange_elems: doubles the exchange buffer must hold (the largest exchange). */
 int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange_elems);
+/* The collectives INSIDE the library: hand over the caller's RCCL communicator (ncclComm_t, one
+ * rank per GPU, its rank / size = the partition's) after spllt_hip_set_partition.  From then on
+ * the unchanged spllt_iface.h calls are all a C or Fortran caller needs: spllt_factor enqueues
+ * the rank's subtrees, every exchange of the program (all-reduce of the top tree, or
+ * reduce-scatter to the owners + one broadcast per block-column step, and the flag) between its
+ * pack and unpack on the engine's stream, and the top tree; spllt_wait drains it; spllt_solve
+ * (job 0) adds the two all-reduces of the right-hand sides.  The exchange buffer is then the
+ * library's own.  What the reference's distributed build keeps inside the library too
+ * (src/PaRSEC/spllt_parsec_blk_data.c:33-64, factorize.jdf).  librccl is resolved at run time
+ * from the copy the process already uses.  NULL detaches (the caller drives the exchanges again,
+ * spllt_hip_pending_exchange / spllt_hip_continue). */
+int spllt_hip_set_communicator(void *fkeep, void *nccl_comm);
 /* index of the exchange the handle is waiting for (-1: none, the program has been enqueued
  * to its end) */
 int spllt_hip_pending_exchange(void *fkeep);

@@ -3,7 +3,8 @@
 #   bash scripts/gpu_profile.sh <tag> "<bench.py args>"
 # 1. rocprofv3 --kernel-trace --stats of the default bench command
 # 2. separate rocprofv3 --pmc passes (kernel-trace only, as the pool requires): FETCH_SIZE,
-#    WRITE_SIZE (HBM traffic), SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe use)
+#    WRITE_SIZE (HBM traffic), SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (matrix-pipe use),
+#    TCC_HIT_sum + TCC_MISS_sum (L2 hit rate)
 # Outputs under gpurun_out/prof_<tag>/; scripts/profile_summary.py turns them into profiles/.
 set -o pipefail
 TAG=$1; ARGS=$2
@@ -27,9 +28,10 @@ check_pass() {   # name, rc, log
 }
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py $B > $OUT/trace.log 2>&1
 check_pass trace $? $OUT/trace.log
-for C in FETCH_SIZE WRITE_SIZE MFMA_BUSY; do
+for C in FETCH_SIZE WRITE_SIZE MFMA_BUSY L2; do
   case $C in
     MFMA_BUSY) CTRS="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE";;
+    L2) CTRS="TCC_HIT_sum TCC_MISS_sum";;     # L2 hit rate per dispatch (MI355X_MICROARCH.md, L2)
     *) CTRS=$C;;
   esac
   timeout -k 10 500 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python3 $REPO/bench.py $B > $OUT/pmc_$C.log 2>&1

@@ -127,6 +127,11 @@ def main():
         prog["mfma_busy"], prog["gui_active"] = c["SQ_VALU_MFMA_BUSY_CYCLES"].values, c["GRBM_GUI_ACTIVE"].values
     else:
         prog["mfma_busy"] = prog["gui_active"] = np.nan
+    c = counters(os.path.join(d, "pmc_L2"))
+    if c is not None and len(c) == len(prog) and "TCC_HIT_sum" in c:
+        prog["l2_hit"], prog["l2_miss"] = c["TCC_HIT_sum"].values, c["TCC_MISS_sum"].values
+    else:
+        prog["l2_hit"] = prog["l2_miss"] = np.nan
     prog["hbm_bytes"] = (2 * prog["fetch_kb"] + prog["write_kb"]) * 1024
     rows = []
     for key, g in list(prog.groupby("cat")) + list(prog[prog["kind"] == 1].groupby("kernel")):
@@ -139,6 +144,8 @@ def main():
                      "alg_GB": round(g["alg_bytes"].sum() / 1e9, 3), "hbm_GB": round(g["hbm_bytes"].sum() / 1e9, 3),
                      "hbm_over_alg": round(g["hbm_bytes"].sum() / g["alg_bytes"].sum(), 2) if g["alg_bytes"].sum() > 0 else None,
                      "hbm_GBps": round(g["hbm_bytes"].sum() / t / 1e9, 1) if t > 0 else 0.0,
+                     "l2_hit_pct": round(float(100 * g["l2_hit"].sum() / (g["l2_hit"].sum() + g["l2_miss"].sum())), 1)
+                     if (g["l2_hit"].sum() + g["l2_miss"].sum()) > 0 else None,
                      "scatter_entries_M": round(g["entries"].sum() / 1e6, 1) if key == "between" else None,
                      "scatter_atomic_GBps": round(8 * g["entries"].sum() / t / 1e9, 1) if key == "between" and t > 0 else None})
     table = pd.DataFrame(rows)

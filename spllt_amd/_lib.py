@@ -56,7 +56,7 @@ HIP_SYMBOLS = [
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
     "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program",
-    "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix",
+    "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix", "spllt_hip_set_communicator",
 ]
 
 _lib = None
@@ -174,5 +174,7 @@ def load():
         fn.restype = C.c_int
     lib.spllt_hip_free_matrix.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     lib.spllt_hip_free_matrix.restype = None
+    lib.spllt_hip_set_communicator.argtypes = [vp, vp]
+    lib.spllt_hip_set_communicator.restype = C.c_int
     _lib = lib
     return lib

@@ -267,6 +267,13 @@ class Factorization:
         self.rank, self.nranks = rank, nranks
         return n.value
 
+    def set_communicator(self, nccl_comm):
+        """hand the caller's RCCL communicator (ncclComm_t as an integer) to the library: the
+        exchanges of the partition then run inside spllt_factor / spllt_wait / spllt_solve"""
+        rc = self.lib.spllt_hip_set_communicator(self.fkeep, C.c_void_p(nccl_comm))
+        if rc < 0:
+            raise SplltError("spllt_hip_set_communicator", rc, self.last_error())
+
     def set_exchange_buffer(self, dev_ptr):
         rc = self.lib.spllt_hip_set_exchange_buffer(self.fkeep, C.c_void_p(dev_ptr))
         if rc < 0:

@@ -384,7 +384,8 @@ void spllt_solve(void* fkeep, spllt_options_t* options, int* order, int nrhs, do
   int rc = do_wait(f);
   if (rc == 0 && !f->eng) rc = SPLLT_ERROR_PARAMETER;  // nothing factorized yet
   if (rc) { if (info) info->flag = rc; return; }
-  if (f->eo.nranks > 1) {
+  if (f->eo.nranks > 1 && !f->eng->has_communicator()) {
+    // (with spllt_hip_set_communicator the engine runs the two all-reduces itself, below)
     // A partitioned factor is spread over the ranks (own subtrees + replicated top
     // tree); this process holds only its part, so a local substitution would be
     // wrong.  The partitioned solve is spllt_hip_solve_dev in three phases with the
@@ -646,6 +647,21 @@ void* spllt_hip_engine_stream(void* fkeep) {
     f->eng->set_exchange_buffer(f->xbuf);
   }
   return (void*)f->eng->stream();
+}
+
+int spllt_hip_set_communicator(void* fkeep, void* nccl_comm) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S) return SPLLT_ERROR_PARAMETER;
+  if (f->dead) return SPLLT_ERROR_HIP;
+  if (!f->eng) {
+    f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+    if (!f->eng) return SPLLT_ERROR_ALLOCATION;
+    f->eng->set_exchange_buffer(f->xbuf);
+  }
+  if (f->eng->status()) { f->last_error = f->eng->error(); return f->eng->status(); }
+  int rc = f->eng->set_communicator(nccl_comm);
+  if (rc) f->last_error = f->eng->error();
+  return rc;
 }
 
 int spllt_hip_set_exchange_buffer(void* fkeep, void* dev_ptr) {

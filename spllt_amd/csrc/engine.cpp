@@ -9,6 +9,8 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <dlfcn.h>
+
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -959,6 +961,146 @@ int Engine::post_exchange(const Launch& X) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// RCCL, resolved at run time from the librccl the process already has (the caller created the
+// communicator with it; a Python process has torch's copy): no link-time dependency, one copy.
+// ---------------------------------------------------------------------------
+namespace {
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_reducescatter_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_broadcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_group_t)();
+typedef int (*nccl_query_t)(void*, int*);
+typedef const char* (*nccl_errstr_t)(int);
+struct Rccl {
+  void* handle = nullptr;
+  nccl_allreduce_t all_reduce = nullptr;
+  nccl_reducescatter_t reduce_scatter = nullptr;
+  nccl_broadcast_t broadcast = nullptr;
+  nccl_group_t group_start = nullptr, group_end = nullptr;
+  nccl_query_t comm_count = nullptr, comm_user_rank = nullptr;
+  nccl_errstr_t err_string = nullptr;
+  bool ok() const { return all_reduce && reduce_scatter && broadcast && group_start && group_end && comm_count && comm_user_rank; }
+};
+constexpr int kNcclDouble = 8, kNcclSum = 0;      // ncclFloat64, ncclSum (rccl.h)
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl q;
+    const char* names[] = {"librccl.so.1", "librccl.so", "libnccl.so.2"};
+    for (const char* nm : names)
+      if ((q.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;     // the copy the process already uses
+    if (!q.handle)
+      for (const char* nm : names)
+        if ((q.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!q.handle) return q;
+    q.all_reduce = (nccl_allreduce_t)dlsym(q.handle, "ncclAllReduce");
+    q.reduce_scatter = (nccl_reducescatter_t)dlsym(q.handle, "ncclReduceScatter");
+    q.broadcast = (nccl_broadcast_t)dlsym(q.handle, "ncclBroadcast");
+    q.group_start = (nccl_group_t)dlsym(q.handle, "ncclGroupStart");
+    q.group_end = (nccl_group_t)dlsym(q.handle, "ncclGroupEnd");
+    q.comm_count = (nccl_query_t)dlsym(q.handle, "ncclCommCount");
+    q.comm_user_rank = (nccl_query_t)dlsym(q.handle, "ncclCommUserRank");
+    q.err_string = (nccl_errstr_t)dlsym(q.handle, "ncclGetErrorString");
+    return q;
+  }();
+  return r;
+}
+}  // namespace
+
+#define NCCLCHK(call, what)                                                                      \
+  do {                                                                                           \
+    int r__ = (call);                                                                            \
+    if (r__ != 0) {                                                                              \
+      status_ = kErrHip;                                                                         \
+      err_ = std::string(what) + ": RCCL error " + std::to_string(r__) +                         \
+             (rccl().err_string ? std::string(" (") + rccl().err_string(r__) + ")" : std::string()); \
+      std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());                                     \
+      return kErrHip;                                                                            \
+    }                                                                                            \
+  } while (0)
+
+int Engine::set_communicator(void* nccl_comm) {
+  if (status_) return status_;
+  if (!nccl_comm) { comm_ = nullptr; return 0; }
+  Rccl& R = rccl();
+  if (!R.ok()) return fail(-10, "spllt_hip_set_communicator: librccl is not loadable", hipSuccess);
+  int cnt = 0, rk = 0;
+  NCCLCHK(R.comm_count(nccl_comm, &cnt), "ncclCommCount");
+  NCCLCHK(R.comm_user_rank(nccl_comm, &rk), "ncclCommUserRank");
+  // SPLLT_HIP_COMM_REHEARSAL=1: a communicator smaller than the partition is accepted (one-GPU
+  // rehearsal of the call sequence: the sums then miss the other ranks' parts, broadcast roots
+  // are taken modulo its size)
+  static const bool rehearsal = std::getenv("SPLLT_HIP_COMM_REHEARSAL") != nullptr;
+  if ((cnt != opt_.nranks || rk != opt_.rank) && !rehearsal) {
+    err_ = "spllt_hip_set_communicator: the communicator is rank " + std::to_string(rk) + " of " + std::to_string(cnt) +
+           ", the partition (spllt_hip_set_partition) is rank " + std::to_string(opt_.rank) + " of " +
+           std::to_string(opt_.nranks);
+    std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
+    return -10;
+  }
+  comm_ = nccl_comm;
+  comm_rank_ = rk;
+  comm_size_ = cnt;
+  if (!xbuf_ && prog_.xbuf_elems > 0) {      // the exchange buffer is the library's own in this mode
+    HIPCHK(dalloc((void**)&xbuf_, sizeof(double) * (size_t)prog_.xbuf_elems), "hipMalloc(exchange buffer)");
+    HIPCHK(hipMemset(xbuf_, 0, sizeof(double) * (size_t)prog_.xbuf_elems), "hipMemset(exchange buffer)");
+  }
+  if (opt_.nranks > 1 && !d_owned_) {
+    // a rank's share of a distributed vector: its own subtrees; rank 0 also the top tree
+    std::vector<double> keep((size_t)S_->n, 0.0);
+    for (int s = 0; s < S_->nnodes; ++s) {
+      const int own = owner_[(size_t)s];
+      const bool mine = own == opt_.rank || (own < 0 && opt_.rank == 0);
+      if (mine)
+        for (int p = S_->sptr[s]; p < S_->sptr[s + 1]; ++p) keep[(size_t)p] = 1.0;
+    }
+    HIPCHK(dev_upload(&d_owned_, keep), "upload owner mask");
+  }
+  return 0;
+}
+
+// the collective of one exchange on the exchange buffer, in place, enqueued on the engine's stream
+// (between pre_exchange's pack and post_exchange's unpack)
+int Engine::collective(const Exchange& E) {
+  Rccl& R = rccl();
+  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) {
+    NCCLCHK(R.all_reduce(xbuf_, xbuf_, (size_t)E.elems, kNcclDouble, kNcclSum, comm_, stream_), "ncclAllReduce");
+  } else if (E.kind == X_REDUCE_OWNER) {
+    // in place: rank r receives into its own chunk of the send buffer
+    NCCLCHK(R.reduce_scatter(xbuf_, xbuf_ + (int64_t)comm_rank_ * E.chunk, (size_t)E.chunk, kNcclDouble, kNcclSum,
+                             comm_, stream_), "ncclReduceScatter");
+  } else if (E.kind == X_BCAST) {
+    // one broadcast per root (the items of a root are contiguous in the buffer), as one group
+    NCCLCHK(R.group_start(), "ncclGroupStart");
+    for (int i = E.first_item; i < E.first_item + E.nitems;) {
+      const ExchangeItem& a = prog_.xitems[(size_t)i];
+      int64_t cnt = 0;
+      int j = i;
+      for (; j < E.first_item + E.nitems && prog_.xitems[(size_t)j].root == a.root &&
+             prog_.xitems[(size_t)j].xoff == a.xoff + cnt; ++j)
+        cnt += prog_.xitems[(size_t)j].count;
+      NCCLCHK(R.broadcast(xbuf_ + a.xoff, xbuf_ + a.xoff, (size_t)cnt, kNcclDouble, a.root % comm_size_, comm_, stream_),
+              "ncclBroadcast");
+      i = j;
+    }
+    NCCLCHK(R.group_end(), "ncclGroupEnd");
+  }
+  return 0;
+}
+
+int Engine::run_exchanges() {
+  if (status_) return status_;
+  while (awaiting_exchange_) {
+    if (!comm_) return 0;                     // the caller drives the exchanges (spllt_hip_continue)
+    const Exchange& E = prog_.exchanges[(size_t)prog_.launches[cur_x_].first];
+    int rc = collective(E);
+    if (rc) return rc;
+    rc = continue_after_exchange();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int Engine::sync_phase() {
   if (status_) return status_;
   for (hipStream_t st : streams_)
@@ -992,6 +1134,7 @@ int Engine::factor_async_dev(const double* val_dev, int64_t nnz) {
   HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
   int rc = enqueue_program();
   if (rc) return rc;
+  if (comm_ && (rc = run_exchanges())) return rc;
   HIPCHK(hipEventRecord(ev1_, stream_), "event");
   pending_ = true;
   stats_.submit_ms = now_ms() - t0;
@@ -1018,6 +1161,7 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
   crumb("factor: enqueueing the program");
   int rc = enqueue_program();
   if (rc) return rc;
+  if (comm_ && (rc = run_exchanges())) return rc;
   crumb("factor: enqueued");
   HIPCHK(hipEventRecord(ev1_, stream_), "event");
   pending_ = true;
@@ -1137,8 +1281,24 @@ int Engine::solve(double* x_host, int nrhs, int job) {
       for (int i = 0; i < n; ++i) yq[S.order[i]] = xr[i];
     }
     HIPCHK(hipMemcpyAsync(d_y_, yh.data(), sizeof(double) * (size_t)n * cur, hipMemcpyHostToDevice, stream_), "rhs H2D");
-    rc = solve_dev(d_y_, cur, job, -1);
-    if (rc) return rc;
+    if (comm_ && opt_.nranks > 1) {
+      // partitioned solve inside the library (every rank passes the same right-hand sides and gets
+      // the same solution): forward substitution on the own subtrees, all-reduce of the vector,
+      // the top tree on every rank, backward substitution on the own subtrees, all-reduce
+      if (job != 0) return -98;
+      Rccl& R = rccl();
+      launch_mask(stream_, d_y_, d_owned_, n, cur, (int64_t)n);
+      if ((rc = solve_dev(d_y_, cur, 0, 0))) return rc;
+      NCCLCHK(R.all_reduce(d_y_, d_y_, (size_t)n * cur, kNcclDouble, kNcclSum, comm_, stream_), "ncclAllReduce(rhs)");
+      if ((rc = solve_dev(d_y_, cur, 0, 1))) return rc;
+      if ((rc = solve_dev(d_y_, cur, 0, 2))) return rc;
+      launch_mask(stream_, d_y_, d_owned_, n, cur, (int64_t)n);
+      NCCLCHK(R.all_reduce(d_y_, d_y_, (size_t)n * cur, kNcclDouble, kNcclSum, comm_, stream_), "ncclAllReduce(x)");
+      if ((rc = sync_stream(stream_, "solve sync"))) return rc;
+    } else {
+      rc = solve_dev(d_y_, cur, job, -1);
+      if (rc) return rc;
+    }
     HIPCHK(hipMemcpy(yh.data(), d_y_, sizeof(double) * (size_t)n * cur, hipMemcpyDeviceToHost), "x D2H");
     for (int q = 0; q < cur; ++q) {
       double* xr = x_host + (int64_t)(done + q) * n;

@@ -88,6 +88,16 @@ class Engine {
   bool awaiting_exchange() const { return awaiting_exchange_; }
   // index (into program().exchanges) of the exchange the engine is waiting for, -1: none
   int pending_exchange() const { return awaiting_exchange_ ? (int)prog_.launches[cur_x_].first : -1; }
+  // ---- the collectives inside the library (RCCL over xGMI): with a communicator set,
+  // factor_async* does not stop at the exchange points -- every exchange of the program
+  // (all-reduce of the top tree / reduce-scatter to the owners + one broadcast per block-column
+  // step / the flag) is enqueued on the engine's stream between its pack and its unpack, and
+  // the solve adds its two all-reduces of the right-hand sides.  What the reference's
+  // distributed build has inside the library too (src/PaRSEC/spllt_parsec_blk_data.c:33-64,
+  // factorize.jdf).  comm: the caller's ncclComm_t, one rank per GPU.
+  int set_communicator(void* nccl_comm);
+  bool has_communicator() const { return comm_ != nullptr; }
+  int run_exchanges();              // all pending exchanges, enqueue only
   int sync_phase();                 // drain the streams at the exchange point
   int continue_after_exchange();
   const std::vector<int>& owners() const { return owner_; }
@@ -170,6 +180,10 @@ class Engine {
   size_t cur_x_ = 0;                // launch index of the exchange the engine waits for
   std::vector<int> top_owner_;      // per block column: owner in a distributed top tree (else empty)
   double* xbuf_ = nullptr;          // caller-owned device buffer of xchg_elems_ doubles
+  void* comm_ = nullptr;            // ncclComm_t (set_communicator)
+  int comm_rank_ = 0, comm_size_ = 1;
+  int collective(const Exchange& E);
+  double* d_owned_ = nullptr;       // per pivot position: 1.0 where this rank contributes to a distributed vector
   std::vector<int> owner_;          // per node: owning rank or -1 (top tree)
   std::vector<int> top_bcols_;      // block columns of the top tree, in order
   std::vector<char> map_keep_;      // per val->L map entry: scattered on this rank?

@@ -1966,6 +1966,17 @@ __global__ void k_flag_pack(const int* __restrict__ flag, double* __restrict__ s
 __global__ void k_flag_unpack(const double* __restrict__ slot, int* __restrict__ flag) {
   if (*slot > 0.5 && *flag == 0x7fffffff) *flag = 0x7ffffffe;   // failed on another rank
 }
+__global__ __launch_bounds__(256) void k_mask(double* __restrict__ y, const double* __restrict__ keep, int n,
+                                              int nrhs, int64_t ldy) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double k = keep[i];
+  for (int q = 0; q < nrhs; ++q) y[q * ldy + i] *= k;
+}
+void launch_mask(hipStream_t st, double* y, const double* keep, int n, int nrhs, int64_t ldy) {
+  if (n <= 0 || nrhs <= 0) return;
+  hipLaunchKernelGGL(k_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, keep, n, nrhs, ldy);
+}
 void launch_flag_pack(hipStream_t st, const int* flag, double* slot) {
   hipLaunchKernelGGL(k_flag_pack, dim3(1), dim3(1), 0, st, flag, slot);
 }

@@ -40,6 +40,8 @@ void launch_gather(const LaunchSink& st, const GatherTile* tiles, int64_t count,
 // multi-GPU: not-positive-definite flag <-> extra element of the exchange buffer
 void launch_flag_pack(hipStream_t st, const int* flag, double* slot);
 void launch_flag_unpack(hipStream_t st, const double* slot, int* flag);
+// y[q * ldy + i] *= keep[i]  (multi-GPU solve: a rank's share of a distributed vector)
+void launch_mask(hipStream_t st, double* y, const double* keep, int n, int nrhs, int64_t ldy);
 // debug: fill the LDS of every CU with signalling NaNs
 void launch_poison_lds(hipStream_t st);
 void launch_update(const LaunchSink& st, int tile, const UpdTile* tiles, int64_t count,

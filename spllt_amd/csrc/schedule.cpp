@@ -125,6 +125,65 @@ struct Builder {
       std::stable_sort(t64.begin(), t64.end(), by_work);
       std::stable_sort(t32.begin(), t32.end(), by_work);
     }
+    // XCD-aware order of a throughput launch.  Workgroup b runs on XCD b % 8 (round-robin
+    // dispatch; each XCD has its own 4 MiB L2), and about `cap` workgroups of the launch are
+    // resident per XCD at a time.  In the plain order (unit by unit, tile column by tile column)
+    // the tiles resident on one XCD at a time are a scattered eighth of ~8 cap consecutive
+    // tiles: every operand strip (128 or 64 rows x K) is fetched by nearly every XCD that holds
+    // one of its tiles -- 3-5 x the algorithmic bytes on the large configurations
+    // (profiles/r02/serena/categories.csv).  Here the tiles of a unit are cut into BANDS of
+    // ~cap tiles (a few tile rows x all tile columns of the unit), the bands are dealt to the
+    // XCDs in turn (heaviest first: the longest-first order of the launch is kept), and the
+    // launch order interleaves the eight sequences -- so the workgroups resident on an XCD form
+    // a compact 2-D block of ONE unit that walks K together: its A strips are shared by all
+    // tile columns, its B strips by all its rows.
+    static const int64_t xcd_order_env = env_int("SPLLT_XCD_ORDER", 1);
+    auto xcd_order = [&](std::vector<UpdTile>& tv, int T) {
+      const size_t cap = T == 128 ? 64 : (T == 64 ? 160 : 256);
+      if (!xcd_order_env || tv.size() < 8 * cap) return;
+      std::vector<std::vector<UpdTile>> seq(8);
+      size_t band = 0, i = 0;
+      while (i < tv.size()) {
+        size_t j = i;
+        int tjmin = tv[i].tj, tjmax = tv[i].tj;
+        while (j < tv.size() && tv[j].unit == tv[i].unit) {
+          tjmin = std::min<int>(tjmin, tv[j].tj);
+          tjmax = std::max<int>(tjmax, tv[j].tj);
+          ++j;
+        }
+        const size_t ntj = (size_t)(tjmax - tjmin + 1);
+        const int R = (int)std::max<size_t>(1, cap / ntj);       // tile rows per band
+        std::vector<UpdTile> u(tv.begin() + (long)i, tv.begin() + (long)j);
+        std::stable_sort(u.begin(), u.end(), [R](const UpdTile& a, const UpdTile& b) {
+          const int ga = a.ti / R, gb = b.ti / R;
+          if (ga != gb) return ga < gb;
+          if (a.tj != b.tj) return a.tj < b.tj;
+          return a.ti < b.ti;
+        });
+        for (size_t k = 0; k < u.size();) {
+          const int g = u[k].ti / R;
+          std::vector<UpdTile>& dst = seq[band++ % 8];
+          for (; k < u.size() && u[k].ti / R == g; ++k) dst.push_back(u[k]);
+        }
+        i = j;
+      }
+      std::vector<UpdTile> out;
+      out.reserve(tv.size());
+      size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t p = 0; p < tv.size(); ++p) {
+        size_t r = p % 8;
+        if (pos[r] >= seq[r].size()) {                   // this XCD's share is used up: the fullest one's
+          size_t best = 0, left = 0;
+          for (size_t q = 0; q < 8; ++q)
+            if (seq[q].size() - pos[q] > left) { left = seq[q].size() - pos[q]; best = q; }
+          r = best;
+        }
+        out.push_back(seq[r][pos[r]++]);
+      }
+      tv.swap(out);
+    };
+    xcd_order(t128, 128);
+    xcd_order(t64, 64);
     // useful flops of ONE tile of a unit, the convention of the whole program (and of the
     // reference's symbolic count): 2 K per entry the tile really computes for the destination
     // (entries above the diagonal of a unit that straddles it do not count); TRSM: the

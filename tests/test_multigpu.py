@@ -197,6 +197,81 @@ def _rccl_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _rccl_inlib_worker(rank, world, port, ret, flags):
+    """one process, one GPU, a ONE-rank RCCL communicator created with the process's own librccl
+    (ncclGetUniqueId + ncclCommInitRank through ctypes: no torch.distributed involved)"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(0)
+    os.environ["SPLLT_HIP_COMM_REHEARSAL"] = "1"
+    from helpers import lower_mask, make_case, rel_err
+    from spllt_amd import matgen
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        A = matgen.nd_like((12, 11, 10), 2)
+        # (a) the library drives the exchanges itself on the communicator
+        f, val = make_case(A, nb=64, nemin=16, prune=True, ncpu=2, engine_flags=flags)
+        f.set_partition(0, 2)
+        f.set_communicator(comm.value)
+        nx = len(f.program("exchanges"))
+        got = f.factor(val).wait().get_factor()
+        assert f.pending_exchange() < 0
+        b = A @ np.ones(f.n)
+        f.solve(b)                                   # (two all-reduces inside; one rank: its own share only)
+        # (b) the caller drives them (spllt_hip_pending_exchange / spllt_hip_continue) and does
+        # what collectives over ONE rank do to the buffer: nothing
+        g, _ = make_case(A, nb=64, nemin=16, prune=True, ncpu=2, engine_flags=flags)
+        xe = g.set_partition(0, 2)
+        xbuf = torch.zeros(max(xe, 1), dtype=torch.float64, device="cuda")
+        g.set_exchange_buffer(xbuf.data_ptr())
+        dval = torch.tensor(val, device="cuda")
+        torch.cuda.synchronize()
+        g.factor_dev(dval.data_ptr())
+        n2 = 0
+        while g.pending_exchange() >= 0:
+            g.wait()
+            g.continue_after_exchange()
+            n2 += 1
+        ref = g.wait().get_factor()
+        ret[0] = (nx, n2, float(rel_err(got, ref, lower_mask(f))), bool(np.isfinite(got).all()))
+        f.close()
+        g.close()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top", ["replicated", "distributed"])
+def test_exchanges_inside_the_library_on_rccl_single_rank(top):
+    """spllt_hip_set_communicator: with the caller's ncclComm_t the library runs the exchange loop
+    of the partition itself -- ncclAllReduce / in-place ncclReduceScatter / grouped ncclBroadcast
+    on the engine's stream between pack and unpack -- so that spllt_factor / spllt_wait /
+    spllt_solve of the unchanged C-ABI are all a one-process-per-GPU caller needs (the reference's
+    distributed build: src/PaRSEC/spllt_parsec_blk_data.c:33-64).  This box has one GPU: rank 0 of
+    a 2-rank partition on a ONE-rank communicator (rehearsal switch), against the same program with
+    the caller driving the exchanges; the multi-rank semantics are covered over gloo."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    flags = 16384 if top == "replicated" else 8192
+    mp.spawn(_rccl_inlib_worker, args=(1, 0, ret, flags), nprocs=1, join=True)
+    nx, n2, err, finite = ret[0]
+    assert nx == n2 and nx >= (1 if top == "replicated" else 3)
+    assert finite and err <= 1e-12, ret[0]
+
+
 @pytest.mark.gpu
 def test_run_exchange_calls_on_rccl_single_rank():
     """The collectives of multigpu.run_exchange (all-reduce, reduce_scatter_tensor into the
