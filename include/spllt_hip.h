@@ -149,6 +149,11 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * pipeline and no early slices.
  * Bit 13 / bit 14 = (multi-GPU) top tree distributed over the ranks / replicated on every rank
  * (default: by the weight of the top tree, see spllt_hip_set_partition).
+ * Bit 15 / bit 16 = HIP-graph replay of the factorization (analyse once, factorize many): one
+ * graph per pattern built from the program tables, a chain of kernel nodes in program order / the
+ * DAG of the multi-stream program; bit 17 = eager launches (the default: on ROCm 7.2
+ * hipGraphLaunch submits nothing before all ~650 nodes are enqueued, 1.7 ms, and a kernel
+ * boundary costs the device the same 1.3-1.4 us either way: 25.1 / 24.4 ms against 23.7 eager).
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);
@@ -262,6 +267,9 @@ int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int ca
  * other streams run at that moment */
 int spllt_hip_profile_in_program(void *fkeep, const double *val, int nnz, float *ms, int capacity);
 const char *spllt_hip_last_error(const void *fkeep);
+/* flag of the last operation on this handle (0, or an SPLLT error flag): what spllt_wait(void),
+ * which has no way to return it, found when the factorization had run */
+int spllt_hip_last_flag(const void *fkeep);
 const char *spllt_hip_version(void);
 
 #ifdef __cplusplus

@@ -112,7 +112,12 @@ void spllt_solve_worker(void *fkeep, spllt_options_t *options, int *order, int n
                         spllt_inform_t *info, int job, double *workspace, long worksize,
                         void *tm);
 
-/* :115 (src/spllt_mod.F90:172-182) completion barrier: drains every stream */
+/* :115 (src/spllt_mod.F90:172-182) completion barrier: drains every stream.  Like the
+ * reference's (a bare `!$omp taskwait`) it takes no handle and returns nothing: a failure that
+ * only shows when the work has run -- a matrix that is not positive definite (flag -20; the
+ * reference swallows dpotrf's info, kernels_mod:1179-1181), a device that does not drain (-30) --
+ * is reported by the NEXT call on that fkeep that takes `info` (spllt_solve, spllt_factor, ...),
+ * with a message on stderr at once; spllt_hip_last_flag(fkeep) (spllt_hip.h) reads it directly. */
 void spllt_wait(void);
 
 /* :117 (ciface:502-552) prints ||Ax-b||/||b|| style checks to stdout */

@@ -57,6 +57,7 @@ HIP_SYMBOLS = [
     "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program",
     "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix", "spllt_hip_set_communicator",
+    "spllt_hip_last_flag",
 ]
 
 _lib = None
@@ -176,5 +177,7 @@ def load():
     lib.spllt_hip_free_matrix.restype = None
     lib.spllt_hip_set_communicator.argtypes = [vp, vp]
     lib.spllt_hip_set_communicator.restype = C.c_int
+    lib.spllt_hip_last_flag.argtypes = [vp]
+    lib.spllt_hip_last_flag.restype = C.c_int
     _lib = lib
     return lib

@@ -842,6 +842,11 @@ static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int 
   return (int)v.size();
 }
 
+int spllt_hip_last_flag(const void* fkeep) {
+  const Fkeep* f = static_cast<const Fkeep*>(fkeep);
+  return f ? (f->dead ? SPLLT_ERROR_HIP : f->last_flag) : SPLLT_ERROR_PARAMETER;
+}
+
 const char* spllt_hip_last_error(const void* fkeep) {
   const Fkeep* f = static_cast<const Fkeep*>(fkeep);
   return f ? f->last_error.c_str() : "";

@@ -878,9 +878,20 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
   // ---- 1. the panel's diagonal block (the first workgroup stores the inverse and reports a
   // failed pivot; L_pp goes home from the workgroup that read the block last) ---------------
   double* Dg = A + (int64_t)c0 * ld + c0;
-  potrf64(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? (2 | 8) : 6, flag);
+  const bool factored = (u.pad_ & 1) != 0;
+  if (factored) {
+    // the panel was factored by a chain launch: only its inverse is needed here (the lower
+    // triangle comes from the dinv scratch, the rest of the 64 x 64 image is zero)
+    const double* W = dinv + u.dinv_off;
+    for (int e = tid; e < 64 * 64; e += kPanelThreads) {
+      const int r = e >> 6, c = e & 63;
+      sh.X[r * TLD + c] = (r < pn && c <= r) ? W[(int64_t)r * pn + c] : 0.0;
+    }
+  } else {
+    potrf64(sh, Dg, ld, pn, dinv + u.dinv_off, pn, u.gcol, first ? (2 | 8) : 6, flag);
+  }
   __syncthreads();
-  if (last_reader(counters + 2 * tl.unit, u.ntile, &vote)) {
+  if (!factored && last_reader(counters + 2 * tl.unit, u.ntile, &vote)) {
     const int lc = tid & 63;       // a wave-instruction writes (part of) one row
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -957,13 +968,37 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
   }
   d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
   double* Sa = sh.X;                        // the inverse is no longer needed: staging for the own rows
-  for (int k0 = 0; k0 < c0; k0 += 64) {
-    const int kw = min(64, c0 - k0);
-    stage_block(Sa, A + (int64_t)r0 * ld + k0, ld, nr, kw, tid);
-    stage_block(S, A + (int64_t)r1 * ld + k0, ld, pn2, kw, tid);
-    __syncthreads();
-    mma_64(Sa, S, s, jb0, lane, m0, m1);
-    __syncthreads();
+  {
+    // K in 64-column chunks through LDS; the loads of chunk k + 1 fly during the MFMAs of chunk k
+    // (one chunk after the other, loads and MFMAs in turn, was 3-6 us per chunk: a whole global
+    // round trip each, on the critical path of every fused panel step)
+    const int sr = tid >> 3, scl = tid & 7;
+    const double* rowa = A + (int64_t)(r0 + (sr < nr ? sr : nr - 1)) * ld;
+    const double* rowd = A + (int64_t)(r1 + (sr < pn2 ? sr : pn2 - 1)) * ld;
+    double va[8], vd[8];
+    auto fetch = [&](int k0) {
+      const int kw = min(64, c0 - k0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = k0 + (scl + 8 * e < kw ? scl + 8 * e : kw - 1);
+        va[e] = rowa[c];
+        vd[e] = rowd[c];
+      }
+    };
+    if (c0 > 0) fetch(0);
+    for (int k0 = 0; k0 < c0; k0 += 64) {
+      const int kw = min(64, c0 - k0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool in = scl + 8 * e < kw;
+        Sa[sr * TLD + scl + 8 * e] = (sr < nr && in) ? va[e] : 0.0;
+        S[sr * TLD + scl + 8 * e] = (sr < pn2 && in) ? vd[e] : 0.0;
+      }
+      __syncthreads();
+      if (k0 + 64 < c0) fetch(k0 + 64);
+      mma_64(Sa, S, s, jb0, lane, m0, m1);
+      __syncthreads();
+    }
   }
   mma_64(Ui, Xd, s, jb0, lane, m0, m1);
 #pragma unroll

@@ -489,9 +489,13 @@ struct Builder {
       P.dinv_size = o;
     }
     const int64_t fused_max = env_int("SPLLT_FUSED_PANEL_MAX", opt.fused_panel_max);
+    const int64_t lite_max = env_int("SPLLT_LITE_PANEL_MAX", opt.lite_panel_max);
 
     const bool la = opt.lookahead;
-    const bool det = opt.deterministic;
+    const bool det_all = opt.deterministic;
+    // levels below this one assemble their inter-node updates through the buffer + ordered gather
+    // (no atomics) even in the default engine: see ScheduleOptions::buffer_levels
+    const int buffer_levels = (int)env_int("SPLLT_BUFFER_LEVELS", opt.buffer_levels);
     const bool pair_sources = env_int("SPLLT_PAIR_TRAILING", opt.pair_sources ? 1 : 0) != 0;
     auto edge = [&](int stream) {
       Edge e;
@@ -571,6 +575,7 @@ struct Builder {
     for (int lev = 0; lev <= maxlevel; ++lev) {
       const auto& nodes = by_level[lev];
       if (nodes.empty()) continue;
+      const bool det = det_all || lev < buffer_levels;
       int maxnc = 0;
       for (int s : nodes) maxnc = std::max(maxnc, S.node_bcol0[s + 1] - S.node_bcol0[s]);
       // Zones: the inter-node updates at the end of the previous level were issued sorted by
@@ -603,7 +608,7 @@ struct Builder {
         }
         const int ng = cdiv(maxw, cb);
         // Latency-bound step (few row blocks below the panels): one fused launch per panel
-        bool fuse_c = false;
+        bool fuse_c = false, lite_c = false;
         if (opt.fused_panel && cb == pw && pw <= 64) {
           int64_t nt = 0;
           for (int s : nodes) {
@@ -614,6 +619,12 @@ struct Builder {
             nt += std::max(1, cdiv(B.nrow - std::min(pw, B.width), 64));
           }
           fuse_c = nt <= fused_max;
+          // "lite": more row blocks than the fused launch is worth (every workgroup of it factors
+          // the diagonal block itself), but few enough for one round of one workgroup per CU: the
+          // POTRF stays a launch of its own and ONE k_panel launch (PanelUnit flag 1: the panel is
+          // factored, its inverse is in the dinv scratch) does the solve of all rows and the
+          // left-looking update of the next panel -- two launches per panel instead of three
+          lite_c = !fuse_c && !dist2 && nt <= lite_max;
         }
         const int evB_c2 = (la && c >= 2) ? evB_hist[c - 2] : -1;   // bulk (c-2 -> c..)
         const int evB_c1 = (la && c >= 1) ? evB_hist[c - 1] : -1;   // bulk (c-1 -> c+1..)
@@ -635,7 +646,45 @@ struct Builder {
             evD = P.nevents++;
             evD_last = evD;
           }
-          if (fuse_c) {
+          if (lite_c) {
+            // POTRF of the panel, one workgroup per node (as in the unfused steps below)
+            Launch L;
+            L.kind = L_CHAIN;
+            L.level = lev;
+            L.first = (int64_t)P.chain_units.size();
+            L.tile = 0;
+            double fl = 0;
+            for (int s : nodes) {
+              const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
+              if (c >= nc) continue;
+              const int b = S.node_bcol0[s] + c;
+              if (!mine(b)) continue;
+              const BlockCol& B = S.bcols[b];
+              const int c0 = cs;
+              if (c0 >= B.width) continue;
+              const int pn = std::min(pw, B.width - c0);
+              ChainUnit u{};
+              u.off = B.off;
+              u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
+              u.ld = B.width;
+              u.c0 = c0;
+              u.pn = pn;
+              u.cs = cs;
+              u.ce = c0 + pn;
+              u.gcol = S.sptr[s] + B.r0 + c0;
+              P.chain_units.push_back(u);
+              fl += (double)pn * pn * pn / 3.0;
+            }
+            L.count = (int64_t)P.chain_units.size() - L.first;
+            L.flops = fl;
+            L.stream = ST_CHAIN;
+            if (la && g == 0) {
+              L.add_wait(zev(c));    // every inter-node update into block column c
+              L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
+            }
+            if (L.count > 0 || L.wait[0] >= 0) P.launches.push_back(L);
+          }
+          if (fuse_c || lite_c) {
             // the whole panel step in one launch (k_panel): POTRF, the rows below, and the
             // left-looking update of the next panel's columns
             Launch L;
@@ -666,6 +715,7 @@ struct Builder {
               u.gcol = S.sptr[s] + B.r0 + c0;
               const int nt = std::max(1, cdiv(below, 64));
               u.ntile = nt;
+              u.pad_ = lite_c ? 1 : 0;          // flag bit 0: the panel is already factored (chain launch above)
               const int ui = (int)P.panel_units.size();
               P.panel_units.push_back(u);
               for (int t = 0; t < nt; ++t) P.tiles.push_back(UpdTile{ui, (short)t, 0});
@@ -674,12 +724,12 @@ struct Builder {
               P.flops_potrf += fp;
               P.flops_trsm += ft;
               P.flops_update += fu;
-              fl += fp + ft + fu;
+              fl += (lite_c ? 0.0 : fp) + ft + fu;
             }
             L.count = (int64_t)P.tiles.size() - L.first;
             L.flops = fl;
             L.stream = ST_CHAIN;
-            if (la && g == 0) {
+            if (la && g == 0 && !lite_c) {
               L.add_wait(zev(c));    // every inter-node update into block column c
               L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
             }
@@ -689,7 +739,7 @@ struct Builder {
             // through them)
             if (L.count > 0 || L.record >= 0 || L.wait[0] >= 0) P.launches.push_back(L);
           }
-          for (int q = 0; !fuse_c && q < maxq; ++q) {
+          for (int q = 0; !fuse_c && !lite_c && q < maxq; ++q) {
             // (1) chain step: panel q of the sub-tile, one workgroup per node
             {
               Launch L;
@@ -844,7 +894,7 @@ struct Builder {
             if (cs >= B.width) continue;
             const int ce = std::min(B.width, cs + cb);
             if (ce < B.width) {
-              if (fuse_c || !mine(b)) continue;   // part of the panel launch / the owner's business
+              if (fuse_c || lite_c || !mine(b)) continue;   // part of the panel launch / the owner's business
               const int ce2 = std::min(B.width, ce + cb);
               UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
               us_n1.push_back(n1);

@@ -103,7 +103,8 @@ struct PanelUnit {
   int nrow;          // rows of the block column
   int gcol;          // pivot position of column c0 (error reporting)
   int ntile;         // workgroups of the unit (64-row blocks below the panel, at least one)
-  int pad_;
+  int pad_;          // flags: bit 0 = the panel is already factored and inverted (a chain launch ran
+                     // before): the workgroups load inv(L_pp) from the dinv scratch instead
 };
 static_assert(sizeof(PanelUnit) == 48, "PanelUnit layout (mirrored in spllt_amd/api.py)");
 
@@ -248,11 +249,18 @@ struct ScheduleOptions {
                               // CUs are free, and a launch that needs a second round of them loses
                               // what the two saved kernel boundaries gain: 26.3 ms unfused, 25.9 with
                               // 64, 26.3 with 128, 28.4 with 512 on the nd24k stand-in)
+  int lite_panel_max = 0;     // steps with more workgroups than fused_panel_max but at most this many: POTRF
+                              // launch + ONE k_panel launch for the rows (solve + left-looking update; the
+                              // workgroups read the inverted panel instead of factoring it).  0: off
   int tile128_min = 4096;     // launches of up to this many 64-tiles keep 64-tiles (the 128-tile pays when a
                               // launch fills the chip for several rounds; throughput-bound problems: 1024)
   bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
+  int buffer_levels = 0;      // the inter-node updates of the tree levels below this one go through the
+                              // buffer + ordered gather as well (the lowest levels have narrow sources:
+                              // their scatter-adds are bound by the chip's ~1.3 TB/s of fp64 atomics, which
+                              // plain stores + one read-modify-write per destination entry are not)
 };
 
 // Winv slot of panel p of a block column of width w (doubles from the block column's slot 0)

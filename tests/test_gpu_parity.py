@@ -183,6 +183,22 @@ def test_not_positive_definite_is_reported():
     assert e.value.flag == -20
 
 
+def test_void_wait_leaves_the_flag_on_the_handle():
+    """spllt_wait(void) cannot return what it found (reference src/spllt_mod.F90:172-182 is a
+    bare taskwait): the flag stays on the handle -- spllt_hip_last_flag, and the next call that
+    takes `info`."""
+    A = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(40, 40)).tolil()
+    A[17, 17] = -3.0
+    f, val = make_case(A.tocsc(), nb=8, nemin=4)
+    f.factor(val)                      # submits only
+    f.lib.spllt_wait()                 # the reference's completion barrier: no handle, no result
+    assert f.lib.spllt_hip_last_flag(f.fkeep) == -20
+    with pytest.raises(api.SplltError) as e:
+        f.solve(np.ones(f.n))
+    assert e.value.flag == -20
+    f.close()
+
+
 def test_linearity_of_scaling():
     """Size-independent property: chol(c*A) = sqrt(c)*chol(A)."""
     A = matgen.nd_like((10, 9, 8), 2)
