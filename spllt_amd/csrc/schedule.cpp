@@ -490,6 +490,8 @@ struct Builder {
     }
     const int64_t fused_max = env_int("SPLLT_FUSED_PANEL_MAX", opt.fused_panel_max);
     const int64_t lite_max = env_int("SPLLT_LITE_PANEL_MAX", opt.lite_panel_max);
+    int super_panel = (int)env_int("SPLLT_SUPER_PANEL", opt.super_panel);
+    if (super_panel % cb != 0) super_panel = 0;            // (a multiple of the panel width, or off)
 
     const bool la = opt.lookahead;
     const bool det_all = opt.deterministic;
@@ -896,7 +898,19 @@ struct Builder {
             if (ce < B.width) {
               if (fuse_c || lite_c || !mine(b)) continue;   // part of the panel launch / the owner's business
               const int ce2 = std::min(B.width, ce + cb);
-              UpdUnit n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
+              // Left-looking inside the block column: the next panel's columns by everything left of
+              // them.  Block columns wider than a SUPER-PANEL (256 columns) do that only inside the
+              // current super-panel; when one is finished it updates ALL remaining columns of the
+              // block column at once (right-looking, K = 256, N up to nb - 256: a 128-tile GEMM).
+              // Without it the 12 panels of a 768-wide block column re-read everything left of them
+              // (K = 64, 128, ... 704 with N = 64: 5.5 passes over the block column, ~15 TFLOP/s).
+              UpdUnit n1;
+              if (super_panel > 0 && B.width > super_panel && ce % super_panel == 0)
+                n1 = direct_unit(b, ce - super_panel, super_panel, b, ce, B.nrow - ce, ce, B.width - ce);
+              else if (super_panel > 0 && B.width > super_panel)
+                n1 = direct_unit(b, (ce / super_panel) * super_panel, ce % super_panel, b, ce, B.nrow - ce, ce, ce2 - ce);
+              else
+                n1 = direct_unit(b, 0, ce, b, ce, B.nrow - ce, ce, ce2 - ce);
               us_n1.push_back(n1);
               fl_n1 += direct_flops(n1);
             } else {

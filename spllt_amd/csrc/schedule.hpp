@@ -249,6 +249,9 @@ struct ScheduleOptions {
                               // CUs are free, and a launch that needs a second round of them loses
                               // what the two saved kernel boundaries gain: 26.3 ms unfused, 25.9 with
                               // 64, 26.3 with 128, 28.4 with 512 on the nd24k stand-in)
+  int super_panel = 256;      // block columns wider than this: left-looking panel updates only inside a
+                              // super-panel of this many columns, one right-looking update of the rest of
+                              // the block column per finished super-panel (0: left-looking throughout)
   int lite_panel_max = 0;     // steps with more workgroups than fused_panel_max but at most this many: POTRF
                               // launch + ONE k_panel launch for the rows (solve + left-looking update; the
                               // workgroups read the inverted panel instead of factoring it).  0: off
