@@ -301,7 +301,7 @@ def main():
 
         def category(l):
             if l[0] != 1:
-                return {0: "potrf", 4: "chain", 5: "winv", 6: "gather", 7: "panel"}.get(int(l[0]), "other")
+                return {0: "potrf", 4: "chain", 5: "winv", 6: "gather", 7: "panel", 8: "chain", 9: "trsm"}.get(int(l[0]), "other")
             if l[3] == 0:
                 return "marker"
             u = units[int(tiles[int(l[2])]["unit"])]

@@ -52,8 +52,15 @@ def categorize(f):
             continue
         kind, first, count, T = int(l[0]), int(l[2]), int(l[3]), int(l[4])
         rec = dict(kind=kind, tile=T, flops=float(l[5]), entries=0.0, alg_bytes=0.0, cat="other")
-        if kind == 4:
+        if kind in (4, 8):
             rec["cat"] = "chain"
+        elif kind == 9:
+            rec["cat"] = "trsm"
+            for uid in np.unique(tiles[first:first + count]["unit"]):
+                u = units[uid]
+                M, N = float(u["M"]), float(u["N"])
+                rec["entries"] += M * N
+                rec["alg_bytes"] += M * N * 16 + N * N * 8
         elif kind == 7:
             rec["cat"] = "panel"      # fused panel step (k_panel)
         elif kind == 6:

@@ -720,6 +720,10 @@ Engine::~Engine() {
 void Engine::emit_kernel(const Launch& l, const LaunchSink& sink, bool multi) {
   if (l.kind == L_CHAIN) {
     launch_chain_panel(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
+  } else if (l.kind == L_CHAIN2) {
+    launch_chain2(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
+  } else if (l.kind == L_TRSM2) {
+    launch_trsm2(sink, d_tiles_ + l.first, l.count, d_units_, d_L_, d_dinv_);
   } else if (l.kind == L_PANEL) {
     launch_panel(sink, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
   } else if (l.kind == L_GATHER) {

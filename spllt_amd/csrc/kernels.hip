@@ -413,7 +413,8 @@ __device__ __forceinline__ void potrf64_body(PotrfShared& sh, double* __restrict
 //     and X home (a CU stores ~10 B/cycle: 64 KB at the end of the kernel were 4-7 k cycles).
 // flags: bit 1 the caller stores L itself; bit 2 neither the inverse is stored nor a failed pivot
 // reported; bit 3 the upper triangle of the inverse's slot is already zero and stays so (the
-// engine clears the dinv scratch once): only the lower triangle is stored.
+// engine clears the dinv scratch once): only the lower triangle is stored; bit 4 the block is
+// already in sh.T (identity-padded lower triangle), nothing is loaded.
 // ---------------------------------------------------------------------------
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -570,6 +571,13 @@ __device__ __forceinline__ void potrf64_v2(PotrfShared& sh, double* __restrict__
   STAMP(0);
   // identity-padded lower triangle into LDS (see potrf64_body)
   const int lw = tid >> 6, lc = tid & 63;
+  if (flags & 16) {
+    // the caller has put the (identity-padded, lower) block into sh.T itself: only X is cleared
+    if (tid < 256) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) X[(4 * e + lw) * TLD + lc] = 0.0;
+    }
+  } else
   if (tid < 256) {
     // (unconditional loads at clamped addresses; the columns right of the row's diagonal block
     // re-read its last column, which costs no traffic)
@@ -782,9 +790,232 @@ __global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict
   const ChainUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
   const int cq = u.c0 - u.cs;
   // (flags 8: the dinv scratch is cleared when it is allocated, and nothing ever writes above the
-  // diagonal of a slot)
-  potrf64(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, cq + u.pn,
+  // diagonal of a slot; the inverse's rows have the stride of their chain block, schedule.hpp winv_ld)
+  potrf64(sh, L + u.off + (int64_t)u.c0 * u.ld + u.c0, u.ld, u.pn, dinv + u.winv_off + cq, u.ce - u.cs,
           u.gcol, 8, flag);
+}
+
+// out[16 s + .][16 jb + .] for all four column blocks jb of a 64 x 64 product a b^T (k over 64),
+// for the 4-wave kernels (mma_64 twice)
+__device__ __forceinline__ void mma_64(const double* __restrict__ a, const double* __restrict__ b, int s,
+                                       int jb0, int lane, d4& acc0, d4& acc1);
+__device__ __forceinline__ void mma_64x4(const double* __restrict__ a, const double* __restrict__ b, int s,
+                                         int lane, d4 (&acc)[4]);
+
+// ---------------------------------------------------------------------------
+// One step of the panel chain for a CHAIN BLOCK of two panels (ChainUnit with pn = its width cw,
+// 64 < cw <= 128; narrower blocks take the one-panel path inside): with [L00 0; L10 L11] the
+// Cholesky factor of the cw x cw diagonal block,
+//   L00 = chol(A00), W00 = inv(L00)                    (potrf64)
+//   L10 = A10 W00^T                                     (64 x 64 x 64 on the matrix cores)
+//   L11 = chol(A11 - L10 L10^T), W11 = inv(L11)         (potrf64 on the block updated in LDS)
+//   W10 = -W11 (L10 W00)                                (two more 64^3 products)
+// and [W00 0; W10 W11] goes to the dinv scratch as ONE cw x cw matrix (row stride cw), so that the
+// rows below are solved for both panels by one product (k_update, TRSM mode, N = K = cw) and the
+// left-looking update of the next chain block runs once per 128 columns.  Six dependent launches
+// per 128 columns of the panel chain become three; the ~3 us of in-LDS products replace a TRSM
+// launch, an in-panel update launch and three kernel boundaries.
+// LDS: PotrfShared + two 64 x TLD buffers (L10, W00^T), as k_panel: one workgroup per CU.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_potrf2(const ChainUnit* __restrict__ units,
+                                                      double* __restrict__ L,
+                                                      double* __restrict__ dinv,
+                                                      int* __restrict__ flag, const ChainUnit u0) {
+  extern __shared__ __attribute__((aligned(16))) double chain2_smem[];
+  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(chain2_smem);
+  double* U = chain2_smem + sizeof(PotrfShared) / sizeof(double);   // L10
+  double* V = U + 64 * TLD;                                          // W00^T
+  __builtin_amdgcn_s_setprio(3);
+  const ChainUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int cw = u.pn, ld = u.ld;
+  double* A00 = L + u.off + (int64_t)u.c0 * ld + u.c0;
+  double* D00 = dinv + u.winv_off;                // cw x cw, row stride cw
+  const int n0 = min(64, cw), n1 = cw - n0;
+  potrf64(sh, A00, ld, n0, D00, cw, u.gcol, 8, flag);
+  if (n1 <= 0) return;
+  __syncthreads();                                // the tail of potrf64 still read sh.T / sh.X
+  double* A10 = A00 + (int64_t)64 * ld;
+  double* A11 = A10 + 64;
+  double* D10 = D00 + (int64_t)64 * cw;
+  double* D11 = D10 + 64;
+  // V = W00^T; sh.T <- A10 (n1 x 64, zero padded: L00 has gone home)
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    V[c * TLD + r] = sh.X[r * TLD + c];
+  }
+  {
+    // lane = column, the four waves take rows w, w + 4, ...: one wave-instruction reads one row
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + wave;
+      v[e] = A10[(int64_t)(r < n1 ? r : n1 - 1) * ld + lane];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + wave;
+      sh.T[r * TLD + lane] = r < n1 ? v[e] : 0.0;
+    }
+  }
+  __syncthreads();
+  // L10 = A10 W00^T -> U (LDS) and home
+  {
+    d4 acc[4];
+    mma_64x4(sh.T, sh.X, wave, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wave * 16 + lq + 4 * r;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const int j = jb * 16 + lr;
+        U[i * TLD + j] = acc[jb][r];
+        if (i < n1) A10[(int64_t)i * ld + j] = acc[jb][r];
+      }
+    }
+  }
+  __syncthreads();
+  // sh.T <- A11 - L10 L10^T (lower triangle, identity padding): the input of the second POTRF
+  {
+    d4 acc[4];
+    mma_64x4(U, U, wave, lane, acc);
+    double a11[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wave * 16 + lq + 4 * r;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const int j = jb * 16 + lr;
+        a11[jb][r] = A11[(int64_t)min(i, n1 - 1) * ld + min(j, n1 - 1)];
+      }
+    }
+    __syncthreads();                              // everybody has read A10's image in sh.T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wave * 16 + lq + 4 * r;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const int j = jb * 16 + lr;
+        sh.T[i * TLD + j] = (i < n1 && j <= i) ? a11[jb][r] - acc[jb][r] : ((i == j) ? 1.0 : 0.0);
+      }
+    }
+  }
+  __syncthreads();
+  potrf64(sh, A11, ld, n1, D11, cw, u.gcol + 64, 8 | 16, flag);
+  __syncthreads();
+  // W10 = -W11 (L10 W00): P = L10 W00 = U V^T (V = W00^T), kept transposed in sh.T (L11 has gone home)
+  {
+    d4 acc[4];
+    mma_64x4(U, V, wave, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wave * 16 + lq + 4 * r;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) sh.T[(jb * 16 + lr) * TLD + i] = acc[jb][r];
+    }
+  }
+  __syncthreads();
+  {
+    d4 acc[4];
+    mma_64x4(sh.X, sh.T, wave, lane, acc);        // W11 P
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wave * 16 + lq + 4 * r;
+      if (i >= n1) continue;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) D10[(int64_t)i * cw + jb * 16 + lr] = -acc[jb][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The rows below a chain block, solved by its inverse: X = A[rows, block] W^T (a12 spllt_solve_block,
+// kernels_mod:1217-1229, as a product), one workgroup per 64 rows and ALL cw <= 128 columns of the
+// block (UpdTile: unit, ti; the unit a TRSM-mode UpdUnit with N = K = cw).  Latency is what counts
+// here (a launch has a few dozen workgroups and the next chain step waits for it): the whole
+// 64 x cw row block and the three 64 x 64 blocks of W are requested at once, then
+//   X0 = A0 W00^T,  X1 = A0 W10^T + A1 W11^T
+// on the matrix cores from LDS, in place (a workgroup reads all it needs before it writes).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm2(const UpdTile* __restrict__ tiles,
+                                               const UpdUnit* __restrict__ units,
+                                               double* __restrict__ L,
+                                               const double* __restrict__ dinv) {
+  extern __shared__ __attribute__((aligned(16))) double trsm2_smem[];
+  double* A0 = trsm2_smem;
+  double* A1 = A0 + 64 * TLD;
+  double* Wb = A1 + 64 * TLD;
+  double* Wc = Wb + 64 * TLD;
+  __builtin_amdgcn_s_setprio(3);
+  const UpdTile tl = tiles[blockIdx.x];
+  const UpdUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int cw = u.N, ld = u.d_ld, ldw = u.dinv_ld;
+  const int n0 = min(64, cw), n1 = cw - n0;
+  const int r0 = (int)tl.ti * 64, nr = min(64, u.M - r0);
+  double* X = L + u.d_off + (int64_t)(u.d_row0 + r0) * ld + u.d_col0;
+  const double* W = dinv + u.dinv_off;
+  // lane = column, the four waves take rows w, w + 4, ...: one wave-instruction reads one row
+  // (512 contiguous bytes); unconditional loads at clamped addresses, all in flight at once
+  const int cl0 = min(lane, n0 - 1), cl1 = min(lane, max(n1 - 1, 0));
+  double a0[16], a1[16], w00[16], w10[16], w11[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int r = 4 * e + wave;
+    a0[e] = X[(int64_t)(r < nr ? r : nr - 1) * ld + cl0];
+    w00[e] = W[(int64_t)(r < n0 ? r : n0 - 1) * ldw + cl0];
+  }
+  if (n1 > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + wave;
+      const double* wr = W + (int64_t)(64 + (r < n1 ? r : n1 - 1)) * ldw;
+      a1[e] = X[(int64_t)(r < nr ? r : nr - 1) * ld + 64 + cl1];
+      w10[e] = wr[lane];
+      w11[e] = wr[64 + cl1];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int r = 4 * e + wave;
+    A0[r * TLD + lane] = (r < nr && lane < n0) ? a0[e] : 0.0;
+    Wb[r * TLD + lane] = (r < n0 && lane < n0) ? w00[e] : 0.0;
+  }
+  if (n1 > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + wave;
+      A1[r * TLD + lane] = (r < nr && lane < n1) ? a1[e] : 0.0;
+      Wc[r * TLD + lane] = r < n1 ? w10[e] : 0.0;
+    }
+  }
+  __syncthreads();
+  d4 x0[4], x1[4];
+  mma_64x4(A0, Wb, wave, lane, x0);                   // A0 W00^T
+  if (n1 > 0) {
+    mma_64x4(A0, Wc, wave, lane, x1);                 // A0 W10^T
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 4 * e + wave;
+      Wb[r * TLD + lane] = (r < n1 && lane < n1) ? w11[e] : 0.0;
+    }
+    __syncthreads();
+    mma_64(A1, Wb, wave, 0, lane, x1[0], x1[1]);      // + A1 W11^T
+    mma_64(A1, Wb, wave, 2, lane, x1[2], x1[3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = wave * 16 + lq + 4 * r;
+    if (i >= nr) continue;
+    double* xr = X + (int64_t)i * ld;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const int j = jb * 16 + lr;
+      if (j < n0) xr[j] = x0[jb][r];
+      if (j < n1) xr[64 + j] = x1[jb][r];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -837,6 +1068,14 @@ __device__ __forceinline__ void mma_64(const double* __restrict__ a, const doubl
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b0[kt], acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b1[kt], acc1, 0, 0, 0);
   }
+}
+
+__device__ __forceinline__ void mma_64x4(const double* __restrict__ a, const double* __restrict__ b, int s,
+                                         int lane, d4 (&acc)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  mma_64(a, b, s, 0, lane, acc[0], acc[1]);
+  mma_64(a, b, s, 2, lane, acc[2], acc[3]);
 }
 
 // "I have read the shared block": true for the workgroup that says so last (it also clears the
@@ -1667,14 +1906,15 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
   for (int pp = 0; pp < np; ++pp) {
     const int p = BWD ? np - 1 - pp : pp;
     const int c0 = p * pw, pn = min(pw, w - c0);
-    // dinv slot of panel p: pn x (cq + pn) with cq = 0 (chain block = panel), inv(L_pp) = its last pn columns
+    // inv(L_pp) inside the inverse of its chain block (schedule.hpp winv_offset / winv_ld): the
+    // chain block's cw x cw matrix, rows from c0 - g0, columns from c0 - g0
+    const int g0 = (c0 / u.cb) * u.cb, ldw = min(u.cb, w - g0);
     int64_t slot = u.dinv_off;
-    for (int t = 0; t < p; ++t) {
-      const int ct = t * pw, pt = min(pw, w - ct);
-      slot += (int64_t)pt * (ct % u.cb + pt);
+    for (int t = 0; t < g0; t += u.cb) {
+      const int64_t cwt = min(u.cb, w - t);
+      slot += cwt * cwt;
     }
-    const int ldw = c0 % u.cb + pn;
-    const double* D = dinv + slot + (ldw - pn);
+    const double* D = dinv + slot + (int64_t)(c0 - g0) * ldw + (c0 - g0);
     if (!BWD) {
       // rows of inv(L_pp) for the second half, requested before the first half's loads
       double dv[4][4];
@@ -1930,6 +2170,34 @@ void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t co
                         int* flag, const ChainUnit& unit0) {
   if (count <= 0) return;
   emit(st, k_chain_potrf, dim3((unsigned)count), dim3(256), 0, units, L, dinv, flag, unit0);
+}
+
+void launch_chain2(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+                   int* flag, const ChainUnit& unit0) {
+  if (count <= 0) return;
+  const unsigned lds = (unsigned)(sizeof(PotrfShared) + sizeof(double) * 2 * 64 * TLD);
+  thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    (void)hipFuncSetAttribute((const void*)k_chain_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_dev = dev;
+  }
+  emit(st, k_chain_potrf2, dim3((unsigned)count), dim3(256), lds, units, L, dinv, flag, unit0);
+}
+
+void launch_trsm2(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
+                  const double* dinv) {
+  if (count <= 0) return;
+  const unsigned lds = (unsigned)(sizeof(double) * 4 * 64 * TLD);
+  thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    (void)hipFuncSetAttribute((const void*)k_trsm2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_dev = dev;
+  }
+  emit(st, k_trsm2, dim3((unsigned)count), dim3(256), lds, tiles, units, L, dinv);
 }
 
 void launch_panel(const LaunchSink& st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,

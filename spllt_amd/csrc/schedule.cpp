@@ -468,9 +468,14 @@ struct Builder {
 
   void run() {
     P.pw = pw;
-    // chain block = one panel.  (ScheduleOptions::cb once selected wider diagonal sub-tiles walked
-    // by a single-workgroup chain kernel; slower at every setting and removed, see kernels.hip.)
-    const int cb = pw;
+    // chain block = two panels, factored (and inverted) by ONE workgroup of k_chain_potrf2; the
+    // rows below are solved for both panels by one product with the 2 pw x 2 pw inverse and the
+    // left-looking update runs once per chain block: three dependent launches per 128 columns
+    // instead of six.  (chain2 off: one panel per chain step, the round-2 shape.  Round 2's wider
+    // "chain blocks" walked by a chain kernel that also solved and updated rows are gone.)
+    const bool chain2 = env_int("SPLLT_CHAIN2", opt.chain2 ? 1 : 0) != 0;
+    const int cb = chain2 ? 2 * pw : pw;
+    const int pq = cb;                       // columns one chain step factors
     P.cb = cb;
     const int nn = S.nnodes;
     int maxlevel = -1;
@@ -483,7 +488,7 @@ struct Builder {
       for (int b = 0; b < S.nbcol(); ++b) {
         dinv_slot[b] = o;
         const int w = S.bcols[b].width;
-        o += winv_offset(w, pw, cb, cdiv(w, pw));
+        o += winv_total(w, cb);
       }
       dinv_slot[S.nbcol()] = o;
       P.dinv_size = o;
@@ -637,7 +642,7 @@ struct Builder {
             const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
             if (c >= nc) continue;
             const int w = S.bcols[S.node_bcol0[s] + c].width;
-            if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pw));
+            if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pq));
           }
           // "block column final" event: only after the last chunk of the step (what the bulk / far
           // streams and the level end wait for); it rides on the chunk's last chain-stream launch --
@@ -745,7 +750,7 @@ struct Builder {
             // (1) chain step: panel q of the sub-tile, one workgroup per node
             {
               Launch L;
-              L.kind = L_CHAIN;
+              L.kind = chain2 ? L_CHAIN2 : L_CHAIN;
               L.level = lev;
               L.first = (int64_t)P.chain_units.size();
               L.tile = 0;
@@ -756,10 +761,10 @@ struct Builder {
                 const int b = S.node_bcol0[s] + c;
                 if (!mine(b)) continue;
                 const BlockCol& B = S.bcols[b];
-                const int c0 = cs + q * pw;
+                const int c0 = cs + q * pq;
                 if (c0 >= std::min(B.width, cs + cb)) continue;
                 const int ce = std::min(B.width, cs + cb);
-                const int pn = std::min(pw, ce - c0);
+                const int pn = std::min(pq, ce - c0);
                 ChainUnit u{};
                 u.off = B.off;
                 u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
@@ -798,10 +803,10 @@ struct Builder {
               const int b = S.node_bcol0[s] + c;
               if (!mine(b)) continue;
               const BlockCol& B = S.bcols[b];
-              const int c0 = cs + q * pw;
+              const int c0 = cs + q * pq;
               if (c0 >= std::min(B.width, cs + cb)) continue;
               const int ce = std::min(B.width, cs + cb);
-              const int pn = std::min(pw, ce - c0);
+              const int pn = std::min(pq, ce - c0);
               const int rows = B.nrow - ce;
               if (rows <= 0) continue;
               UpdUnit u{};
@@ -823,14 +828,38 @@ struct Builder {
               u.k0 = cs;
               u.klen = c0 - cs + pn;
               u.dinv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
-              u.dinv_ld = c0 - cs + pn;
+              u.dinv_ld = winv_ld(B.width, cb, c0);
               us.push_back(u);
               const double ft = (double)rows * pn * pn, fu = 2.0 * rows * pn * (c0 - cs);
               P.flops_trsm += ft;
               P.flops_update += fu;
               fl += ft + fu;
             }
-            {
+            static const int64_t trsm2_max = env_int("SPLLT_TRSM2_MAX", 2048);
+            int64_t nt64 = 0;
+            for (const UpdUnit& u : us) nt64 += cdiv(u.M, 64);
+            if (chain2 && !us.empty() && nt64 <= trsm2_max) {
+              // one workgroup per 64 rows and all columns of the chain block (k_trsm2)
+              Launch L;
+              L.kind = L_TRSM2;
+              L.level = lev;
+              L.first = (int64_t)P.tiles.size();
+              L.tile = 64;
+              L.flops = fl;
+              L.stream = ST_CHAIN;
+              L.record = evD;
+              L.lat = 1;
+              for (UpdUnit& u : us) {
+                const int uid = (int)P.units.size();
+                u.a_w = S.bcols[u.src_bcol0].width;
+                u.a_off = S.bcols[u.src_bcol0].off;
+                P.units.push_back(u);
+                for (int ti = 0; ti < cdiv(u.M, 64); ++ti) P.tiles.push_back(UpdTile{uid, (short)ti, 0});
+              }
+              L.count = (int64_t)P.tiles.size() - L.first;
+              P.launches.push_back(L);
+              us.clear();
+            } else {
               Edge e = edge(ST_CHAIN);
               e.record = evD;        // (an empty launch still forwards the event)
               e.lat = 1;
@@ -1183,7 +1212,7 @@ void build_solve_program(const Symbolic& S, int pw, int cb, SolveProgram& P, con
       u.nrow = B.nrow;
       u.pw = pw;
       u.cb = cb;
-      o += winv_offset(B.width, pw, cb, (B.width + pw - 1) / pw);
+      o += winv_total(B.width, cb);
     }
   }
   int maxlevel = -1;

@@ -134,7 +134,16 @@ struct GatherTile {
 static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
 
 enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, /* 5: removed */ L_GATHER = 6,
-                        L_PANEL = 7 };
+                        L_PANEL = 7, L_CHAIN2 = 8, L_TRSM2 = 9 };
+// L_TRSM2 (k_trsm2): the rows below a chain block solved by its inverse, X = A[:, block] W^T, one
+// workgroup per 64 rows and ALL the block's columns (tiles: unit, ti; TRSM-mode UpdUnits with
+// N = K = the block's width): the whole K extent of a row block is requested at once instead of
+// in 16-column steps (a tile of the throughput kernel needs 26 us for K = 128: eight dependent
+// round trips to memory).
+// L_CHAIN2 (k_chain_potrf2): one workgroup factors a whole CHAIN BLOCK of two panels (ChainUnit with
+// pn = its width, up to 2 kPanelMax) and emits its full inverse, so that the rows below are solved
+// for both panels by ONE product and updated by one launch: three launches per 128 columns of the
+// panel chain instead of six.
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
 // (the side stream id is reserved: a variant that ran the rows below the sub-tiles one step
@@ -223,6 +232,13 @@ struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
   int cb = 64;          // ignored (chain block of the removed sub-tile chain kernels)
+  bool chain2 = false;  // chain blocks of TWO panels (L_CHAIN2 + L_TRSM2: three dependent launches per 128
+                        // columns of the panel chain instead of six); false: one panel per chain step.
+                        // Parity-clean and measured equal (23.66 vs 23.77 ms on the bench workload, 320.3
+                        // vs 318.7 on serena_like): what the saved launches gain, the 64^3 products of one
+                        // workgroup on ONE CU (1.7 us each: an fp64 MFMA holds a SIMD's matrix pipe for 64
+                        // cycles) take back -- k_chain_potrf2 34 us against 2 x 13.8, k_trsm2 14 us against
+                        // 2 x 8.  Off by default (SPLLT_CHAIN2=1).
   // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree
   // node, -1 for the (replicated) top tree.  With nranks > 1 the program is
   // [own subtrees] EXCHANGE [top tree].
@@ -266,14 +282,33 @@ struct ScheduleOptions {
                               // plain stores + one read-modify-write per destination entry are not)
 };
 
-// Winv slot of panel p of a block column of width w (doubles from the block column's slot 0)
-inline int64_t winv_offset(int w, int pw, int cb, int p) {
+// dinv scratch of a block column of width w: per CHAIN BLOCK (cb columns from column g0 = 0, cb,
+// 2 cb, ...; the last one ragged) one square cw x cw row-major matrix, cw = min(cb, w - g0): the
+// inverse of that diagonal block of L (lower triangle; what lies above the diagonal is zero and is
+// never written).  The rows of panel p (first column c0 = p pw) start at winv_offset; the row
+// stride is winv_ld.  With cb = pw a chain block is one panel and the slot is the pn x pn inverse.
+inline int winv_ld(int w, int cb, int c0) {
+  const int g0 = (c0 / cb) * cb;
+  return cb < w - g0 ? cb : w - g0;
+}
+inline int64_t winv_total(int w, int cb) {
   int64_t o = 0;
-  for (int t = 0; t < p; ++t) {
-    const int ct = t * pw, pt = (pw < w - ct) ? pw : w - ct;
-    o += (int64_t)pt * (ct % cb + pt);
+  for (int g0 = 0; g0 < w; g0 += cb) {
+    const int64_t cw = cb < w - g0 ? cb : w - g0;
+    o += cw * cw;
   }
   return o;
+}
+inline int64_t winv_offset(int w, int pw, int cb, int p) {
+  const int c0 = p * pw;
+  if (c0 >= w) return winv_total(w, cb);
+  const int g0 = (c0 / cb) * cb;
+  int64_t o = 0;
+  for (int t = 0; t < g0; t += cb) {
+    const int64_t cw = cb < w - t ? cb : w - t;
+    o += cw * cw;
+  }
+  return o + (int64_t)(c0 - g0) * winv_ld(w, cb, c0);
 }
 
 void build_program(const Symbolic& S, const ScheduleOptions& opt, Program& P);

@@ -81,8 +81,9 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 arena[dd[low]] = Lb[low]
                 inv = sl.solve_triangular(Lb, np.eye(pn), lower=True)
                 wo = int(q["winv_off"])
-                Wv = dinv[wo:wo + pn * (cq + pn)].reshape(pn, cq + pn)   # view: only the inverse part
-                Wv[:, cq:] = inv
+                ldw = ce - cs                                            # row stride: the chain block's width
+                Wv = dinv[wo:wo + pn * ldw].reshape(pn, ldw)             # view: the panel's rows of the block's inverse
+                Wv[:, cq:cq + pn] = inv
                 if ce > c0 + pn:
                     xi = idx(c0 + pn, ce, c0, c0 + pn)
                     X = arena[xi] @ inv.T
@@ -90,6 +91,19 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                     ti = idx(c0 + pn, ce, c0 + pn, ce)
                     keep = np.tril(np.ones((ce - c0 - pn,) * 2, dtype=bool))
                     arena[ti[keep]] -= (X @ X.T)[keep]
+            continue
+        if kind == 8:  # a chain block of two panels per unit (k_chain_potrf2): factor + full inverse
+            for q in f.program("chains")[first:first + count]:
+                ld, off = int(q["ld"]), int(q["off"])
+                c0, cw = int(q["c0"]), int(q["pn"])
+                assert int(q["cs"]) == c0 and int(q["ce"]) == c0 + cw and cw <= 128
+                dd = off + np.arange(c0, c0 + cw)[:, None] * ld + np.arange(c0, c0 + cw)[None, :]
+                blk = np.tril(arena[dd])
+                Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
+                low = np.tril_indices(cw)
+                arena[dd[low]] = Lb[low]
+                wo = int(q["winv_off"])
+                dinv[wo:wo + cw * cw] = sl.solve_triangular(Lb, np.eye(cw), lower=True).ravel()
             continue
         if kind == 7:  # one whole panel step per launch (k_panel), workgroup by workgroup
             pu = f.program("panels")
@@ -171,6 +185,9 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             u = units[int(t["unit"])]
             i0, j0 = int(t["ti"]) * T, int(t["tj"]) * T
             mi, nj = min(T, int(u["M"]) - i0), min(T, int(u["N"]) - j0)
+            if kind == 9:          # k_trsm2: 64 rows x ALL columns of the chain block per workgroup
+                assert u["mode"] == MODE_TRSM and j0 == 0 and T == 64
+                nj = int(u["N"])
             assert mi > 0 and nj > 0
             P = np.zeros((mi, nj))
             for sg in range(int(u["nseg"])):

@@ -603,6 +603,29 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("flags", [0, 2, 512, 4096])
+@pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((12, 11, 10), 2), 160, 32),
+                                       (lambda: matgen.nd_like((14, 13, 12), 3), 256, None),
+                                       (lambda: matgen.fe27((9, 8, 8), 3), 200, 48)])
+def test_two_panel_chain_blocks_match_oracle(flags, gen, nb, pw, monkeypatch):
+    """SPLLT_CHAIN2=1: chain blocks of two panels -- k_chain_potrf2 factors a 128-wide diagonal
+    block and emits its whole inverse, k_trsm2 solves the rows below for both panels at once, the
+    left-looking update runs once per chain block (three dependent launches per 128 columns of
+    the panel chain instead of six); the dinv scratch then holds one cw x cw matrix per chain
+    block, which the device solve reads too."""
+    monkeypatch.setenv("SPLLT_CHAIN2", "1")
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=16, panel_width=pw, engine_flags=flags)
+    kinds = f.program("launches")[:, 0]
+    assert (kinds == 8).any() and (kinds == 9).any() and not (kinds == 4).any() and not (kinds == 7).any()
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val)
+    assert rc == 0
+    assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = A @ np.ones(f.n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
+
+
 @pytest.mark.parametrize("flags", [2, 64, 66, 256, 512, 1024, 2048, 4096, 4098])
 @pytest.mark.parametrize("cb", [None, 32, 96, 160])
 def test_engine_variants_match_oracle(flags, cb):

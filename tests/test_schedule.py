@@ -141,6 +141,15 @@ def _access_sets(f):
                 R.append((b, c0, ce, c0, ce))
                 W.append((b, c0, ce, c0, ce))
                 W.append(("wi", b, c0 // pw))      # inverse part of Winv
+        elif kind == 8:
+            # a chain block of two panels: factor of its diagonal block + the block's whole inverse
+            for q in chains[first:first + count]:
+                b = bcol_of(q["off"])
+                c0, cw = int(q["c0"]), int(q["pn"])
+                R.append((b, c0, c0 + cw, c0, c0 + cw))
+                W.append((b, c0, c0 + cw, c0, c0 + cw))
+                for p in range(c0 // pw, (c0 + cw - 1) // pw + 1):
+                    W.append(("wi", b, p))
         elif kind == 2:
             # exchange: the pack reads, the unpack overwrites whole block columns (engine.cpp
             # pre_exchange / post_exchange)
@@ -183,7 +192,7 @@ def _access_sets(f):
                 b = bcol_of(t["d_off"])
                 r0, c0 = int(t["row0"]), int(t["col0"])
                 W.append((b, r0, r0 + int(t["rows"]), c0, c0 + int(t["cols"])))
-        elif kind == 1:
+        elif kind in (1, 9):
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 u = units[uid]
                 db = bcol_of(u["d_off"]) if u["mode"] != 3 else -1
@@ -203,7 +212,8 @@ def _access_sets(f):
                     W.append(("scratch", 0, 0))
                     continue
                 if u["mode"] == 2:
-                    R.append(("wi", db, dc0 // pw))
+                    for p in range(dc0 // pw, (dc0 + N - 1) // pw + 1):    # the inverses of the panels it solves with
+                        R.append(("wi", db, p))
                     if int(u["klen"]) > N:
                         R.append(("ww", db, dc0 // pw))
                     W.append((db, dr0, dr0 + M, dc0, dc0 + N))
@@ -277,21 +287,27 @@ def dag_violations(f):
                                         (lambda: matgen.nd_like((9, 8, 8), 2), 100, 8)])
 @pytest.mark.parametrize("cb", [0, 8, 16, 40])
 @pytest.mark.parametrize("flags", [0, 64, 512, 1024, 2048, 2560, 4096, 4160, 4608])
-def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, monkeypatch):
+@pytest.mark.parametrize("chain2", [1, 0])
+def test_stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain2, monkeypatch):
     """Multi-stream program (chain, side, bulk, far, wide): any two launches that touch the
     same entries (write/write, read/write, atomic/plain) must be ordered by stream order or
-    an event edge; concurrent atomics into one destination are fine.  cb: chain block smaller
-    than the block column, so that block columns are walked in several sub-tiles."""
+    an event edge; concurrent atomics into one destination are fine.  cb: the (ignored) chain
+    block knob; chain2: chain blocks of two panels (k_chain_potrf2 + k_trsm2) or one panel per
+    chain step (with the fused k_panel launches; the default)."""
     if cb:
         monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
+    monkeypatch.setenv("SPLLT_CHAIN2", str(chain2))
     A = gen()
     f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
     bad, launches, before, rec_at, last_in_stream = dag_violations(f)
     assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert not (launches[:, 6] == 3).any(), "the side stream is not used"
-    fused = not flags & 512      # fused panel launches replace the chain steps (the chain block knob is ignored)
-    assert (launches[:, 0] == (7 if fused else 4)).any() and not (launches[:, 0] == (4 if fused else 7)).any()
+    if chain2:
+        assert (launches[:, 0] == 8).any() and not (launches[:, 0] == 4).any() and not (launches[:, 0] == 7).any()
+    else:
+        fused = not flags & 512      # fused panel launches replace the chain steps (the chain block knob is ignored)
+        assert (launches[:, 0] == (7 if fused else 4)).any() and not (launches[:, 0] == (4 if fused else 7)).any()
     assert ((launches[:, 0] == 6).any()) == bool(flags & 4096), "gather launches only in the deterministic engine"
     if flags & 4096:
         units = f.program("units")
@@ -315,18 +331,23 @@ def test_single_stream_program_has_no_events():
 
 @pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048, 4096, 4098, 4608])
 @pytest.mark.parametrize("cb", [0, 16, 32])
-def test_program_variants_agree(flags, cb, monkeypatch):
+@pytest.mark.parametrize("chain2", [1, 0])
+def test_program_variants_agree(flags, cb, chain2, monkeypatch):
     """multi-stream / single-stream programs, with and without early inter-node slices, zone
-    pipeline forced on / off, deterministic engine, one or several panels per diagonal
-    sub-tile: all reproduce the same factor (interpreted in numpy)."""
+    pipeline forced on / off, deterministic engine, chain blocks of two panels or one panel per
+    chain step: all reproduce the same factor (interpreted in numpy)."""
     if cb:
         monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
+    monkeypatch.setenv("SPLLT_CHAIN2", str(chain2))
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
-    assert f.program("chain_block") == 16          # the chain block is one panel, whatever is asked for
+    assert f.program("chain_block") == (32 if chain2 else 16)   # two panels / one, whatever the knob asks for
     kinds = f.program("launches")[:, 0]
     assert not (kinds == 5).any()
-    assert (kinds == 7).any() == (not flags & 512), "fused panel launches unless flag 512"
+    if chain2:
+        assert (kinds == 8).any() and not (kinds == 7).any() and not (kinds == 4).any()
+    else:
+        assert (kinds == 7).any() == (not flags & 512), "fused panel launches unless flag 512"
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
@@ -357,7 +378,7 @@ def test_inter_node_updates_are_sliced_over_the_far_stream(flags):
     assert (partial > 0) == (flags == 0)     # K slices only in the default program
     # one event per zone launch, and the chain steps of later levels wait for far-stream events
     far_events = set(int(e) for e in L[L[:, 6] == 2][:, 7] if e >= 0)
-    chain_waits = set(int(w) for w in L[np.isin(L[:, 0], (4, 7))][:, 8:12].ravel() if w >= 0)   # chain / fused panel steps
+    chain_waits = set(int(w) for w in L[np.isin(L[:, 0], (4, 7, 8))][:, 8:12].ravel() if w >= 0)   # chain / fused panel / chain-block steps
     assert len(far_events & chain_waits) >= 3
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
