@@ -736,6 +736,41 @@ def test_device_solve_jobs_and_multiple_rhs(gen, nb):
     np.testing.assert_allclose(got[:, 1], o.solve(B[:, 1]), rtol=1e-10, atol=1e-11)
 
 
+@pytest.mark.parametrize("nb", [32, 64, 128])
+@pytest.mark.parametrize("prune", [False, True])
+def test_stress_harness_sweep_from_a_matrix_file(nb, prune, tmp_path):
+    """The reference's stress harness (scripts/stress_test.sh:24-128 around test/test_solve_phasis.F90:
+    a Rutherford-Boeing file read with rb_options%values = 3, nb in 32..128, with and without tree
+    pruning, nrhs in 1..10, 16..128, and after every solve the scaled backward error against 1e-14
+    per right-hand side) -- here with the file going through the LIBRARY's reader
+    (spllt_hip_read_rb) and everything else through the C-ABI."""
+    rng = np.random.default_rng(5)
+    M = sp.random(600, 600, density=0.01, random_state=np.random.RandomState(9), format="csr")
+    pat = ((M + M.T) + sp.eye(600)).tocsc()
+    path = tmp_path / "stress.rb"
+    matgen.write_rb(str(path), pat)
+    n, ptr, row, val = matgen.read_file_c(str(path), "rb", values=3)       # diagonally dominant values
+    A = sp.csc_matrix((val, row - 1, ptr - 1), shape=(n, n))
+    A = (A + sp.tril(A, -1).T).tocsc()
+    f = api.Factorization(n, ptr.astype(np.int32), row.astype(np.int32), nb=nb, nemin=8, prune_tree=prune, ncpu=3)
+    f.factor(val).wait()
+    ntest = 0
+    for nrhs in (1, 2, 3, 5, 10, 16, 128):
+        X = rng.standard_normal((n, nrhs))
+        B = A @ X
+        got = f.solve(B if nrhs > 1 else B[:, 0])
+        got = got.reshape(n, nrhs)
+        for r in range(nrhs):
+            assert bwd_err(A, got[:, r], B[:, r]) <= 1e-14, (nrhs, r)
+        ntest += 1
+    # forward and backward sweeps as separate calls (job 1, then job 2), several right-hand sides
+    B = A @ np.ones((n, 4))
+    x = f.solve(f.solve(B, job=1), job=2)
+    np.testing.assert_allclose(x, np.ones((n, 4)), rtol=0, atol=1e-10)
+    assert ntest == 7
+    f.close()
+
+
 def test_bench_workload_full_size_properties():
     """BASELINE config 2 stand-in at its full size (n = 72 324, 755 GFLOP): the
     factor agrees with the CPU oracle (MKL build), the reference's residual bar
