@@ -266,6 +266,11 @@ int spllt_hip_profile(void *fkeep, const double *val, int nnz, float *ms, int ca
  * the stream it runs on (behind its dependency waits), i.e. its duration beside whatever the
  * other streams run at that moment */
 int spllt_hip_profile_in_program(void *fkeep, const double *val, int nnz, float *ms, int capacity);
+/* when every event of the real multi-stream program was reached: t_ms[i] = ms after the value
+ * scatter at which the event that launch i records completed (-1: the launch records none),
+ * t_ms[#launches] = the end of the program.  Nothing is added to the streams (the program's own
+ * records, on timing-enabled events).  Returns #launches + 1. */
+int spllt_hip_timeline(void *fkeep, const double *val, int nnz, float *t_ms, int capacity);
 const char *spllt_hip_last_error(const void *fkeep);
 /* flag of the last operation on this handle (0, or an SPLLT error flag): what spllt_wait(void),
  * which has no way to return it, found when the factorization had run */

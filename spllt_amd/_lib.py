@@ -55,7 +55,7 @@ HIP_SYMBOLS = [
     "spllt_hip_program_get", "spllt_hip_profile", "spllt_hip_last_error", "spllt_hip_version",
     "spllt_hip_set_partition", "spllt_hip_set_exchange_buffer", "spllt_hip_continue",
     "spllt_hip_pending_exchange",
-    "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program",
+    "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program", "spllt_hip_timeline",
     "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix", "spllt_hip_set_communicator",
     "spllt_hip_last_flag",
 ]
@@ -148,6 +148,8 @@ def load():
     lib.spllt_hip_profile.restype = C.c_int
     lib.spllt_hip_profile_in_program.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.spllt_hip_profile_in_program.restype = C.c_int
+    lib.spllt_hip_timeline.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_float), C.c_int]
+    lib.spllt_hip_timeline.restype = C.c_int
     lib.spllt_hip_last_error.argtypes = [vp]
     lib.spllt_hip_last_error.restype = C.c_char_p
     lib.spllt_hip_version.argtypes = []

@@ -320,6 +320,17 @@ class Factorization:
             raise SplltError("spllt_hip_profile", rc, self.last_error())
         return ms[:rc]
 
+    def timeline(self, val):
+        """spllt_hip_timeline: ms after the value scatter at which the event of every recording
+        launch of the real multi-stream program completed (-1: none); last entry = the end"""
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        nl = len(self.program("launches")) + 1
+        t = np.zeros(nl, dtype=np.float32)
+        rc = self.lib.spllt_hip_timeline(self.fkeep, _dp(val), self.nnz, t.ctypes.data_as(C.POINTER(C.c_float)), nl)
+        if rc < 0:
+            raise SplltError("spllt_hip_timeline", rc, self.last_error())
+        return t[:rc]
+
     def last_error(self):
         return (self.lib.spllt_hip_last_error(self.fkeep) or b"").decode()
 

@@ -842,6 +842,19 @@ static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int 
   return (int)v.size();
 }
 
+int spllt_hip_timeline(void* fkeep, const double* val, int nnz, float* t_ms, int capacity) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !val) return SPLLT_ERROR_PARAMETER;
+  if (!f->eng) f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
+  if (!f->eng || f->eng->status()) return SPLLT_ERROR_HIP;
+  std::vector<float> v;
+  int rc = f->eng->timeline(val, nnz, v);
+  if (rc) return rc;
+  for (int i = 0; i < (int)v.size() && i < capacity; ++i) t_ms[i] = v[i];
+  f->hostL_valid = false;
+  return (int)v.size();
+}
+
 int spllt_hip_last_flag(const void* fkeep) {
   const Fkeep* f = static_cast<const Fkeep*>(fkeep);
   return f ? (f->dead ? SPLLT_ERROR_HIP : f->last_flag) : SPLLT_ERROR_PARAMETER;

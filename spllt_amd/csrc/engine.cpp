@@ -1358,6 +1358,52 @@ int Engine::profile_launches(const double* val_host, int64_t nnz, std::vector<fl
   return 0;
 }
 
+// When every event of the real multi-stream program was reached, in ms after the value scatter:
+// the program exactly as factor_async submits it, except that its events are timing-enabled ones
+// of this call (nothing is added to the streams: the records are the program's own).  t[i] = time
+// of the event launch i records (-1: the launch records none); t[nl] = the end of the program.
+int Engine::timeline(const double* val_host, int64_t nnz, std::vector<float>& t) {
+  if (status_) return status_;
+  if (nnz != S_->nnzA) return -10;
+  if (!prog_.exchanges.empty()) return -98;   // single-GPU programs only
+  const Symbolic& S = *S_;
+  HIPCHK(hipSetDevice(device_), "hipSetDevice");
+  HIPCHK(hipMemcpy(d_val_, val_host, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice), "val H2D");
+  HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
+  if (!prog_.panel_units.empty())
+    HIPCHK(hipMemsetAsync(d_panel_cnt_, 0, sizeof(int) * 2 * prog_.panel_units.size(), stream_), "memset counters");
+  *h_flag_ = INT_MAX;
+  HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
+  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
+  const size_t nl = prog_.launches.size();
+  std::vector<hipEvent_t> timed((size_t)prog_.nevents + 2);
+  for (auto& e : timed) HIPCHK(hipEventCreate(&e), "event create");
+  std::vector<hipEvent_t> keep;
+  keep.swap(dag_events_);
+  dag_events_.assign(timed.begin(), timed.begin() + prog_.nevents);
+  hipEvent_t e0 = timed[(size_t)prog_.nevents], e1 = timed[(size_t)prog_.nevents + 1];
+  int rc = 0;
+  hipError_t he = hipEventRecord(e0, stream_);
+  for (int s = 0; s < ST_COUNT && he == hipSuccess; ++s)
+    if (streams_[s] != stream_) he = hipStreamWaitEvent(streams_[s], e0, 0);
+  if (he == hipSuccess) rc = enqueue_range(0, nl);
+  if (he == hipSuccess && !rc && prog_.final_event >= 0) he = hipStreamWaitEvent(stream_, dag_events_[prog_.final_event], 0);
+  if (he == hipSuccess && !rc) he = hipEventRecord(e1, stream_);
+  if (he == hipSuccess && !rc) he = hipStreamSynchronize(stream_);
+  if (he == hipSuccess && !rc) {
+    t.assign(nl + 1, -1.f);
+    for (size_t i = 0; i < nl; ++i) {
+      const int r = prog_.launches[i].record;
+      if (r >= 0) hipEventElapsedTime(&t[i], e0, dag_events_[(size_t)r]);
+    }
+    hipEventElapsedTime(&t[nl], e0, e1);
+  }
+  dag_events_.swap(keep);
+  for (auto& e : timed) hipEventDestroy(e);
+  if (he != hipSuccess) return fail(kErrHip, "timeline", he);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // Submission under a deadline.  Everything spllt_factor does before it returns -- engine
 // creation (stream / event borrowing, allocations, synchronous table upload), the staging of

@@ -121,6 +121,8 @@ class Engine {
   const FactorStats& stats() const { return stats_; }
   // per-launch device time of the last factorization (profiling mode)
   int profile_launches(const double* val_host, int64_t nnz, std::vector<float>& ms, bool serial = true);
+  // when each event of the real program was reached (ms after the value scatter; see engine.cpp)
+  int timeline(const double* val_host, int64_t nnz, std::vector<float>& t);
 
  private:
   int upload();

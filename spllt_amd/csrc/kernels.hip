@@ -46,6 +46,16 @@
 #define UPD128_WN 2
 #endif
 
+// (experiment switch: what the scatter epilogue would cost without atomics -- results are WRONG
+// with it, timing only)
+#if defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 1
+#define SCATTER_ADD(p, v) (*(p) += (v))
+#elif defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 2
+#define SCATTER_ADD(p, v) (*(p) = (v))
+#else
+#define SCATTER_ADD(p, v) unsafeAtomicAdd((p), (v))
+#endif
+
 namespace spx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1255,18 +1265,14 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
 // doubles -> conflict-free ds_read_b64 for the MFMA operand pattern) with the
 // next step's global loads issued before the current step's MFMAs.
 // ---------------------------------------------------------------------------
-template <int T, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __restrict__ tiles,
-                                                const UpdUnit* __restrict__ units,
-                                                const int64_t* __restrict__ bc_off,
-                                                const int* __restrict__ bc_w,
-                                                double* __restrict__ L,
-                                                const int* __restrict__ relpos,
-                                                const int* __restrict__ rlist,
-                                                const double* __restrict__ dinv, int prio) {
-  // latency-critical launches (panel chain) outrank the trailing-update waves
-  // they share a SIMD with
-  if (prio) __builtin_amdgcn_s_setprio(3);
+template <int T, int BK, int WM, int WN, bool NARROW>
+__device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
+                                            const int64_t* __restrict__ bc_off,
+                                            const int* __restrict__ bc_w,
+                                            double* __restrict__ L,
+                                            const int* __restrict__ relpos,
+                                            const int* __restrict__ rlist,
+                                            const double* __restrict__ dinv) {
   // LDS row stride BK + 3 doubles (odd): measured best (scripts/update_bench.hip with
   // -DUPD_LDK_PAD=n).  BK + 2 makes the MFMA operand reads conflict-free but the staging
   // writes collide (SQ_LDS_BANK_CONFLICT = 40 % of the LDS-active cycles); the odd
@@ -1292,12 +1298,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
   double* const As = upd_smem;
   double* const Bs = upd_smem + UPD_STAGES * T * LDK;
 
-  const UpdTile tl = tiles[blockIdx.x];
-  const UpdUnit u = units[tl.unit];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int i0 = tl.ti * T, j0 = tl.tj * T;
   const int M = u.M, N = u.N;
+  // A tile with few columns (the remainder of a unit's N beyond its last full tile column: the
+  // inter-node updates of the bench workload have N = 132..142 in most units, i.e. 4..14 columns
+  // in the third 64-wide tile column) does not need all FMM x FMN fragments per wave:
+  //   narrow 1 (<= 32 columns): wave (wm, wn) keeps its rows and takes column fragment wn alone
+  //   narrow 2 (<= 16 columns): wave w takes row fragment w and column fragment 0
+  // -- half / a quarter of the MFMAs of the step (13 % fewer executed flops in the 64-tile
+  // scatter launches of the bench workload).  The 64-tile instance only (k_update below).
+  // NARROW is a template parameter: the full tiles run the code they always ran.
+  const int narrow = !NARROW ? 0 : (N - j0 <= 16 ? 2 : 1);
+  const int na = narrow == 2 ? 1 : FMM, nbf = narrow ? 1 : FMN;   // fragments this wave computes
+  // fragment (a, b) of this wave: first row / column inside the tile
+  auto roff = [&](int a) { return narrow == 2 ? wave * 16 : wm * (T / WM) + a * 16; };
+  auto coff = [&](int b) { return narrow == 2 ? 0 : (narrow == 1 ? wn * 16 : wn * (T / WN) + b * 16); };
 
   const int srow = tid / TPR;            // tile row staged by this thread
   const int skof = (tid % TPR) * PER;    // first k of its chunk
@@ -1437,6 +1454,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
     }
   };
+  // the narrow tiles: one column fragment per wave, na row fragments
+  auto mfma_small = [&](int st) {
+    const double* Ap = As + st * (T * LDK) + (roff(0) + (lane & 15)) * LDK + (lane >> 4);
+    const double* Bp = Bs + st * (T * LDK) + (coff(0) + (lane & 15)) * LDK + (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const double bv = Bp[ks * 4];
+      const double a0 = Ap[ks * 4];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][0], 0, 0, 0);
+      if (FMM > 1 && na > 1) {
+        const double a1 = Ap[16 * LDK + ks * 4];
+        acc[FMM > 1 ? 1 : 0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[FMM > 1 ? 1 : 0][0], 0, 0, 0);
+      }
+    }
+  };
 #if UPD_STAGES == 2
   if (more) {
     stage(0);
@@ -1447,7 +1479,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
       // stage st holds step k; the loads of step k+1 fly during its MFMAs
       const bool nxt = more;
       if (nxt) load_regs();
-      mfma_step(st);
+      if (NARROW) mfma_small(st); else mfma_step(st);
       if (!nxt) break;
       stage(st ^ 1);        // (everybody left this stage before the last barrier)
       more = advance();
@@ -1462,7 +1494,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
     __syncthreads();
     more = advance();       // the next K step: its global loads fly during the MFMAs
     if (more) load_regs();
-    mfma_step(0);
+    if (NARROW) mfma_small(0); else mfma_step(0);
   }
 #endif
 
@@ -1474,21 +1506,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
     int dcol[FMN];
 #pragma unroll
     for (int b = 0; b < FMN; ++b) {
-      const int j = j0 + wn * (T / WN) + b * 16 + lc;
-      dcol[b] = (j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
+      const int j = j0 + coff(b) + lc;
+      dcol[b] = (b < nbf && j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
     }
 #pragma unroll
     for (int a = 0; a < FMM; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
-        if (i >= M) continue;
+        const int i = i0 + roff(a) + lr + 4 * r;
+        if (i >= M || a >= na) continue;
         const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
 #pragma unroll
         for (int b = 0; b < FMN; ++b) {
-          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          const int j = j0 + coff(b) + lc;
           if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
-            unsafeAtomicAdd(D + drow + dcol[b], -acc[a][b][r]);
+            SCATTER_ADD(D + drow + dcol[b], -acc[a][b][r]);
         }
       }
   } else {
@@ -1507,22 +1539,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
       double cv[4][FMN];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
+        const int i = i0 + roff(a) + lr + 4 * r;
         const double* drow = D + (int64_t)min(i, M - 1) * u.d_ld;
 #pragma unroll
         for (int b = 0; b < FMN; ++b) {
-          const int j = j0 + wn * (T / WN) + b * 16 + lc;
-          ok[r][b] = i < M && j < N && (trsm || !u.lower || u.src_r0 + i >= u.src_c0 + j);
+          const int j = j0 + coff(b) + lc;
+          ok[r][b] = a < na && b < nbf && i < M && j < N && (trsm || !u.lower || u.src_r0 + i >= u.src_c0 + j);
           cv[r][b] = (ok[r][b] && !trsm && !atomic) ? drow[j] : 0.0;
         }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
+        const int i = i0 + roff(a) + lr + 4 * r;
         double* drow = D + (int64_t)min(i, M - 1) * u.d_ld;
 #pragma unroll
         for (int b = 0; b < FMN; ++b) {
-          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          const int j = j0 + coff(b) + lc;
           if (!ok[r][b]) continue;
           if (trsm) drow[j] = acc[a][b][r];
           else if (atomic) unsafeAtomicAdd(drow + j, -acc[a][b][r]);
@@ -1531,6 +1563,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __res
       }
     }
   }
+}
+
+template <int T, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __restrict__ tiles,
+                                                const UpdUnit* __restrict__ units,
+                                                const int64_t* __restrict__ bc_off,
+                                                const int* __restrict__ bc_w,
+                                                double* __restrict__ L,
+                                                const int* __restrict__ relpos,
+                                                const int* __restrict__ rlist,
+                                                const double* __restrict__ dinv, int prio) {
+  // latency-critical launches (panel chain) outrank the trailing-update waves
+  // they share a SIMD with
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const UpdTile tl = tiles[blockIdx.x];
+  const UpdUnit u = units[tl.unit];
+  if (T == 64 && WM == 2 && WN == 2 && u.N - tl.tj * T <= 32)
+    update_body<T, BK, WM, WN, (T == 64 && WM == 2 && WN == 2)>(tl, u, bc_off, bc_w, L, relpos, rlist, dinv);
+  else
+    update_body<T, BK, WM, WN, false>(tl, u, bc_off, bc_w, L, relpos, rlist, dinv);
 }
 
 template <int T, int WM, int WN>
@@ -1721,7 +1773,7 @@ __device__ __forceinline__ void update_dma_body(const UpdTile* __restrict__ tile
         for (int b = 0; b < FMN; ++b) {
           const int j = j0 + wn * (T / WN) + b * 16 + lc;
           if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
-            unsafeAtomicAdd(D + drow + dcol[b], -acc[a][b][r]);
+            SCATTER_ADD(D + drow + dcol[b], -acc[a][b][r]);
         }
       }
   } else {

@@ -255,7 +255,10 @@ def test_solve_block_twin(m, n):
 
 
 @pytest.mark.parametrize("m,n,n1,diag", [(16, 16, 4, 1), (64, 64, 64, 0), (256, 256, 256, 1),
-                                          (300, 200, 77, 0), (260, 256, 100, 1), (33, 17, 5, 0)])
+                                          (300, 200, 77, 0), (260, 256, 100, 1), (33, 17, 5, 0),
+                                          # N = 128 + 11, 64 + 26, 64 + 3: the narrow 64-tiles (one column
+                                          # fragment per wave) beside full ones, with and without a diagonal
+                                          (200, 139, 50, 0), (300, 139, 256, 1), (200, 90, 33, 1), (131, 67, 20, 0)])
 def test_update_block_twin(m, n, n1, diag):
     torch = _torch()
     from oracle import pyoracle
@@ -285,7 +288,8 @@ def test_update_block_twin(m, n, n1, diag):
 
 @pytest.mark.parametrize("blkm,blkn,rls,cls,n1,diag", [(64, 48, 20, 11, 32, 0), (256, 256, 130, 90, 256, 0),
                                                         (128, 128, 70, 70, 40, 1), (256, 200, 150, 120, 9, 1),
-                                                        (32, 32, 1, 1, 3, 0)])
+                                                        (32, 32, 1, 1, 3, 0), (256, 256, 200, 139, 64, 0),
+                                                        (256, 256, 180, 75, 100, 1)])
 def test_update_between_and_expand_buffer_twins(blkm, blkn, rls, cls, n1, diag):
     """fused update_between (GEMM + scatter epilogue) and the stand-alone
     expand_buffer against spo_update_between pieces of the oracle."""
