@@ -10,15 +10,17 @@ for (M, N) in ((8192, 8192), (2048, 2048)):
         A = torch.randn(M, K, dtype=torch.float64, device="cuda")
         B = torch.randn(N, K, dtype=torch.float64, device="cuda")
         C = torch.zeros(M, N, dtype=torch.float64, device="cuda")
-        for _ in range(3):
+        # sustained rate, like scripts/update_bench.hip: ~150 ms of back-to-back calls first (the chip
+        # needs that long under load to reach its clocks), then the average of a timed train
+        est_ms = 2.0 * M * N * K / 40e12 * 1e3 + 0.01
+        nwarm, nrep = int(150.0 / est_ms) + 1, int(60.0 / est_ms) + 3
+        for _ in range(nwarm):
             torch.addmm(C, A, B.t(), beta=1.0, alpha=-1.0, out=C)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nrep):
+            torch.addmm(C, A, B.t(), beta=1.0, alpha=-1.0, out=C)
+        e1.record()
         torch.cuda.synchronize()
-        best = 1e9
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            torch.addmm(C, A, B.t(), beta=1.0, alpha=-1.0, out=C)
-            e1.record()
-            torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1))
+        best = e0.elapsed_time(e1) / nrep
         print(f"M=N={M} K={K:5d}  {best * 1e3:9.1f} us  {2.0 * M * N * K / best / 1e9:7.2f} TFLOP/s", flush=True)

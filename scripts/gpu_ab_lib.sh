@@ -24,4 +24,7 @@ ca=collections.defaultdict(float); cb=collections.defaultdict(float)
 for x in a: ca[x[7]]+=float(x[6])
 for x in b: cb[x[7]]+=float(x[6])
 for k in ca: print("%-10s A %.3f  B %.3f ms (launches alone)" % (k, ca[k], cb.get(k,0)))
+for lev in sorted(set(int(x[2]) for x in a)):
+    sa=sum(float(x[6]) for x in a if x[7]=="between" and int(x[2])==lev); sb=sum(float(x[6]) for x in b if x[7]=="between" and int(x[2])==lev)
+    if sa: print("between, level %2d: A %.3f  B %.3f ms" % (lev, sa, sb))
 PY

@@ -6,7 +6,7 @@ profiler trace (rocprofv3 adds 8-10 us between dependent dispatches) or the brac
 completed; per waiting launch of the chain stream, how long after the previous chain record its own
 wait was satisfied (= how long the chain stood still for another stream).
 
-    python scripts/timeline.py [config] [repeats]
+    python scripts/timeline.py [config] [repeats] [level: list every event of it]
 """
 import os
 import sys
@@ -66,6 +66,14 @@ def main():
     print(f"  chain stream stood still for events of other streams (lower bound: since its last own record): {tot:.2f} ms in {len(stalls)} waits")
     for d, i, ready in sorted(stalls, reverse=True)[:16]:
         print(f"    {d * 1e3:7.1f} us before launch {i} ({KIND.get(int(L[i][0]), L[i][0])}, level {L[i][1]}, count {L[i][3]}), ready at {ready:.3f} ms")
+    if len(sys.argv) > 3:
+        # every event of one level: launch, stream, kind, count, time, the events it waited for
+        lev = int(sys.argv[3])
+        print(f"  events of level {lev}:")
+        for i in range(nl):
+            if L[i][1] == lev and t[i] >= 0:
+                ws = [f"{rec[int(w)]:.3f}" for w in L[i][8:12] if w >= 0]
+                print(f"    launch {i:4d} {NAMES[int(L[i][6])]:5s} {KIND.get(int(L[i][0]), L[i][0]):7s} count {int(L[i][3]):6d} tile {int(L[i][4]):3d}  done {t[i]:8.3f} ms  waited for {ws}")
     f.close()
 
 

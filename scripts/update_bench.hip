@@ -45,16 +45,23 @@ int main(int argc, char** argv) {
       UpdTile* dt;
       hipMalloc(&dt, tl.size() * sizeof(UpdTile));
       hipMemcpy(dt, tl.data(), tl.size() * sizeof(UpdTile), hipMemcpyHostToDevice);
+      // SUSTAINED rate: the chip needs ~100 ms of continuous load to reach its clocks (the first
+      // launches after an idle pause run 15-20 % slower, scripts/sustain_probe.hip); round 2 timed
+      // single launches between synchronisations and read 62 TFLOP/s where the kernel holds 68
       float best = 1e9;
-      for (int r = 0; r < 6; ++r) {
-        hipDeviceSynchronize();
+      {
+        const double est_ms = 2.0 * M * N * K / 40e12 * 1e3 + 0.01;
+        const int nwarm = (int)(150.0 / est_ms) + 1, nrep = (int)(60.0 / est_ms) + 3;
+        for (int r = 0; r < nwarm; ++r)
+          launch_update(0, T, dt, (int64_t)tl.size(), du, bc_off, bc_w, L, nullptr, nullptr, nullptr);
         hipEventRecord(e0);
-        launch_update(0, T, dt, (int64_t)tl.size(), du, bc_off, bc_w, L, nullptr, nullptr, nullptr);
+        for (int r = 0; r < nrep; ++r)
+          launch_update(0, T, dt, (int64_t)tl.size(), du, bc_off, bc_w, L, nullptr, nullptr, nullptr);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) best = ms;
+        best = ms / nrep;
       }
       // one lone tile: latency of a single workgroup
       hipDeviceSynchronize();

@@ -46,6 +46,12 @@
 #define UPD128_WN 2
 #endif
 
+// (experiment switch: waves per SIMD the 64-tile update kernel is compiled for; 0 = as many as its
+// ~90 registers allow (5))
+#ifndef UPD64_OCC
+#define UPD64_OCC 0
+#endif
+
 // (experiment switch: what the scatter epilogue would cost without atomics -- results are WRONG
 // with it, timing only)
 #if defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 1
@@ -1566,7 +1572,7 @@ __device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
 }
 
 template <int T, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_update(const UpdTile* __restrict__ tiles,
+__global__ __launch_bounds__(64 * WM * WN, (T == 64 && UPD64_OCC > 0) ? UPD64_OCC : 2) void k_update(const UpdTile* __restrict__ tiles,
                                                 const UpdUnit* __restrict__ units,
                                                 const int64_t* __restrict__ bc_off,
                                                 const int* __restrict__ bc_w,
