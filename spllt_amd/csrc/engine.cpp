@@ -323,6 +323,7 @@ ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
   // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
   // large configurations; the latency-bound bench workload prefers 4096 (24.5 vs 25.0 ms)
   so.tile128_min = lb ? 4096 : 1024;
+  so.tail_cus = 256 - std::max(opt.reserve_cus, 0);   // (gfx950: 256 CUs)
   return so;
 }
 

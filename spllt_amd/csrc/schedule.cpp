@@ -184,6 +184,103 @@ struct Builder {
     };
     xcd_order(t128, 128);
     xcd_order(t64, 64);
+    // The last, partly filled round of a throughput launch, split along K.  A launch of n tiles
+    // runs in rounds of `slots` workgroups (2 per CU for the 128-tile, 4 for the 64-tile); the
+    // r = n mod slots tiles of the last round occupy r / slots of the chip for a whole tile time
+    // (measured, scripts/update_bench.hip over M: 5.0 rounds of 128-tiles at K = 512 run at 64.7
+    // TFLOP/s, 5.125 rounds at 60.0; the inter-node launches of the bench workload are 2-8 rounds
+    // long).  Inter-node and trailing updates ADD into their destination, so a tile's K range can
+    // be dealt to several workgroups that each add their part (atomically): the last r tiles
+    // become p r workgroups with 1/p of the K extent each, p = slots / r (at most 4, at least 64
+    // columns per piece; 8 workgroups of 32-tiles per CU).  A piece is a unit of its own: the K segments [s0, s1) of the tile's
+    // unit, or a column window of its single segment.
+    const int64_t split_env = env_int("SPLLT_SPLIT_TAIL", -1);      // (read per program: tests switch it)
+    const bool split_on = split_env >= 0 ? split_env != 0 : opt.split_tail;
+    const int64_t tail_cus = env_int("SPLLT_TAIL_CUS", opt.tail_cus);
+    const int min_k = (int)std::max<int64_t>(env_int("SPLLT_SPLIT_MINK", 64), 1);   // columns per piece, at least
+    auto split_tail = [&](std::vector<UpdTile>& tv, int T) {
+      if (!split_on || !throughput || opt.deterministic) return;
+      const size_t slots = (size_t)(T == 128 ? 2 : (T == 64 ? 4 : 8)) * (size_t)std::max<int64_t>(tail_cus, 1);
+      if (tv.size() < slots) return;
+      const size_t r = tv.size() % slots;
+      if (r == 0 || r * 10 >= slots * 7) return;
+      const int p = (int)std::min<size_t>(slots / r, 4);
+      if (p < 2) return;
+      std::vector<UpdTile> tail(tv.end() - (long)r, tv.end());
+      tv.resize(tv.size() - r);
+      std::vector<std::pair<int, std::vector<int>>> done;   // unit -> its pieces (few units per tail)
+      auto pieces_of = [&](int uid) -> const std::vector<int>& {
+        for (const auto& d : done)
+          if (d.first == uid) return d.second;
+        std::vector<int> ids;
+        const UpdUnit u = P.units[(size_t)uid];
+        std::vector<UpdUnit> pcs;
+        if (u.mode == MODE_SCATTER || u.mode == MODE_DIRECT) {
+          if (u.nseg >= 2) {
+            // groups of consecutive K segments of about equal width
+            const int g = std::min(p, u.nseg);
+            int64_t total = 0;
+            for (int sg = 0; sg < u.nseg; ++sg) total += S.bcols[u.src_bcol0 + sg].width;
+            int s0 = 0;
+            int64_t acc = 0;
+            for (int i = 0; i < g && s0 < u.nseg; ++i) {
+              int s1 = s0;
+              const int64_t want = total * (i + 1) / g;
+              do acc += S.bcols[u.src_bcol0 + s1++].width; while (s1 < u.nseg && acc < want && u.nseg - s1 > g - 1 - i);
+              if (i == g - 1) s1 = u.nseg;
+              UpdUnit q = u;
+              q.src_bcol0 = u.src_bcol0 + s0;
+              q.nseg = s1 - s0;
+              q.seg_r0 = u.seg_r0 + s0 * u.seg_stride;
+              if (u.b_bcol0 >= 0) {
+                q.b_bcol0 = u.b_bcol0 + s0;
+                q.b_seg_r0 = u.b_seg_r0 + s0 * u.seg_stride;
+              }
+              q.k0 = 0;
+              q.klen = -1;
+              pcs.push_back(q);
+              s0 = s1;
+            }
+          } else {
+            const int kbeg = u.klen >= 0 ? u.k0 : 0;
+            const int K = u.klen >= 0 ? u.klen : S.bcols[u.src_bcol0].width;
+            const int g = std::min(p, K / min_k);
+            if (g >= 2) {
+              const int step = ((K + g - 1) / g + 15) / 16 * 16;
+              for (int k = 0; k < K; k += step) {
+                UpdUnit q = u;
+                q.k0 = kbeg + k;
+                q.klen = std::min(step, K - k);
+                pcs.push_back(q);
+              }
+            }
+          }
+        }
+        if (pcs.size() < 2) {
+          ids.push_back(uid);
+        } else {
+          for (UpdUnit& q : pcs) {
+            if (q.mode == MODE_DIRECT) q.atomic = 1;   // several workgroups add into the tile now
+            q.a_w = S.bcols[q.src_bcol0].width;
+            q.a_off = S.bcols[q.src_bcol0].off;
+            ids.push_back((int)P.units.size());
+            P.units.push_back(q);
+            us.push_back(q);
+          }
+        }
+        done.push_back({uid, ids});
+        return done.back().second;
+      };
+      for (const UpdTile& t : tail)
+        for (int id : pieces_of(t.unit)) {
+          UpdTile q = t;
+          q.unit = id;
+          tv.push_back(q);
+        }
+    };
+    split_tail(t128, 128);
+    split_tail(t64, 64);
+    split_tail(t32, 32);
     // useful flops of ONE tile of a unit, the convention of the whole program (and of the
     // reference's symbolic count): 2 K per entry the tile really computes for the destination
     // (entries above the diagonal of a unit that straddles it do not count); TRSM: the

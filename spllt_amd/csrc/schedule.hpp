@@ -271,6 +271,13 @@ struct ScheduleOptions {
   int lite_panel_max = 0;     // steps with more workgroups than fused_panel_max but at most this many: POTRF
                               // launch + ONE k_panel launch for the rows (solve + left-looking update; the
                               // workgroups read the inverted panel instead of factoring it).  0: off
+  bool split_tail = false;    // the partly filled last round of a throughput launch is split along K into
+                              // several adding workgroups per tile (SPLLT_SPLIT_TAIL=1).  Parity-clean and
+                              // measured: single launches alone gain 2-4 % where the tail was long and lose up
+                              // to 10 % where the launch is only 1-2 rounds (more atomics, more workgroups);
+                              // 23.07 vs 23.04 ms on the bench workload -- inside the program the other streams
+                              // fill the tails anyway.  Off.
+  int tail_cus = 224;         // ... CUs such a launch runs on (the chip less the reserved CUs)
   int tile128_min = 4096;     // launches of up to this many 64-tiles keep 64-tiles (the 128-tile pays when a
                               // launch fills the chip for several rounds; throughput-bound problems: 1024)
   bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time

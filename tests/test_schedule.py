@@ -280,6 +280,75 @@ def dag_violations(f):
     return bad, launches, before, rec_at, last_in_stream
 
 
+_split_cases = {}
+
+
+@pytest.mark.parametrize("gen,nb,pw,nemin", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16, 8),
+                                              (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8, 8),
+                                              (lambda: matgen.poisson3d(12), 128, 64, 32),
+                                              (lambda: matgen.nd_like((10, 9, 9), 2), 64, 64, 16)])
+@pytest.mark.parametrize("cus", [1, 3, 16])
+@pytest.mark.parametrize("flags", [0, 512])
+def test_launch_tails_split_along_k(gen, nb, pw, nemin, cus, flags, monkeypatch):
+    """The last, partly filled round of a throughput launch is dealt along K to several workgroups
+    per tile (schedule.cpp split_tail): with a chip of 1 / 3 / 16 CUs every test-sized launch has
+    such a tail.  The pieces are units of their own -- K segments or a column window of the
+    tile's unit, adding atomically -- and the program must still order every conflict and give
+    the oracle's numbers."""
+    A = gen()
+    monkeypatch.setenv("SPLLT_SPLIT_TAIL", "0")
+    f0, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
+    u0, t0 = f0.program("units"), f0.program("tiles")
+    monkeypatch.setenv("SPLLT_SPLIT_TAIL", "1")
+    monkeypatch.setenv("SPLLT_TAIL_CUS", str(cus))
+    monkeypatch.setenv("SPLLT_SPLIT_MINK", "8")      # (test-sized block columns: 8-128 columns)
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
+    units, tiles, launches = f.program("units"), f.program("tiles"), f.program("launches")
+    assert len(launches) == len(f0.program("launches"))
+    np.testing.assert_allclose(launches[:, 5].sum(), f0.program("launches")[:, 5].sum(), rtol=1e-12)   # same flops
+    # a piece adds: scatter mode, or a direct unit marked atomic; never a solve / buffered unit
+    bw = f.sym("bcol_width")
+    pieces = 0
+    for l in launches:
+        if l[0] != 1 or l[3] == 0:
+            continue
+        tl = tiles[int(l[2]):int(l[2] + l[3])]
+        seen = {}
+        for t in tl:
+            seen.setdefault((int(t["ti"]), int(t["tj"]), int(units[t["unit"]]["d_off"]), int(units[t["unit"]]["relrow_off"]),
+                             int(units[t["unit"]]["d_row0"]), int(units[t["unit"]]["d_col0"]), int(units[t["unit"]]["src_r0"])), []).append(int(t["unit"]))
+        for key, us in seen.items():
+            if len(us) < 2:
+                continue
+            pieces += len(us)
+            assert l[6] in (1, 2), "only launches of the bulk / far streams are split"
+            ks = []
+            for uid in us:
+                u = units[uid]
+                assert u["mode"] == 1 or (u["mode"] == 0 and u["atomic"] == 1)
+                for sg in range(int(u["nseg"])):
+                    b = int(u["src_bcol0"]) + sg
+                    k0 = int(u["k0"]) if (u["nseg"] == 1 and u["klen"] >= 0) else 0
+                    k1 = k0 + int(u["klen"]) if (u["nseg"] == 1 and u["klen"] >= 0) else int(bw[b])
+                    ks.append((b, k0, k1))
+            ks.sort()
+            for (b0, a0, a1), (b1, c0, c1) in zip(ks, ks[1:]):      # the K ranges of the pieces are disjoint
+                assert b1 > b0 or c0 >= a1, ks
+    assert (pieces > 0) == (len(units) > len(u0))
+    _split_cases[(nb, cus)] = pieces
+    bad, *_ = dag_violations(f)
+    assert not bad, bad[:3]
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+def test_some_launch_tail_is_split():
+    """(after the sweep below) the sweep did split tails: most of its cases, not none"""
+    if not _split_cases:
+        pytest.skip("runs after test_launch_tails_split_along_k in the same process")
+    assert sum(1 for v in _split_cases.values() if v > 0) * 2 >= len(_split_cases), _split_cases
+
+
 @pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
                                         (lambda: matgen.poisson2d(40), 16, 16),
                                         (lambda: matgen.poisson3d(9), 24, 8),
