@@ -58,6 +58,8 @@
 #define SCATTER_ADD(p, v) (*(p) += (v))
 #elif defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 2
 #define SCATTER_ADD(p, v) (*(p) = (v))
+#elif defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 3
+#define SCATTER_ADD(p, v) ((void)(p), (void)(v))
 #else
 #define SCATTER_ADD(p, v) unsafeAtomicAdd((p), (v))
 #endif
@@ -1521,6 +1523,17 @@ __device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + roff(a) + lr + 4 * r;
         if (i >= M || a >= na) continue;
+#if defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 4
+        // (timing only: the 64 lanes of one atomic instruction in ONE destination row, 64 columns
+        // side by side, instead of 4 rows x 16 columns -- what a transposed epilogue would issue)
+        const int64_t drow = (int64_t)(relpos[u.relrow_off + (i - lr)] - u.d_row0) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + coff(b) + lc;
+          if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
+            unsafeAtomicAdd(D + drow + (dcol[b] + 16 * lr) % u.d_ld, -acc[a][b][r]);
+        }
+#else
         const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
 #pragma unroll
         for (int b = 0; b < FMN; ++b) {
@@ -1528,6 +1541,7 @@ __device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
           if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
             SCATTER_ADD(D + drow + dcol[b], -acc[a][b][r]);
         }
+#endif
       }
   } else {
     double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
@@ -1774,6 +1788,15 @@ __device__ __forceinline__ void update_dma_body(const UpdTile* __restrict__ tile
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wm * (T / WM) + a * 16 + lr + 4 * r;
         if (i >= M) continue;
+#if defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 4
+        const int64_t drow = (int64_t)(relpos[u.relrow_off + (i - lr)] - u.d_row0) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + wn * (T / WN) + b * 16 + lc;
+          if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
+            unsafeAtomicAdd(D + drow + (dcol[b] + 16 * lr) % u.d_ld, -acc[a][b][r]);
+        }
+#else
         const int64_t drow = (int64_t)(relpos[u.relrow_off + i] - u.d_row0) * u.d_ld;
 #pragma unroll
         for (int b = 0; b < FMN; ++b) {
@@ -1781,6 +1804,7 @@ __device__ __forceinline__ void update_dma_body(const UpdTile* __restrict__ tile
           if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j))
             SCATTER_ADD(D + drow + dcol[b], -acc[a][b][r]);
         }
+#endif
       }
   } else {
     double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
