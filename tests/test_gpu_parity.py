@@ -871,6 +871,35 @@ def test_host_program_equals_engine_program(gen, nb):
     f.close()
 
 
+def test_timeline_of_the_real_program():
+    """spllt_hip_timeline: one factorization submitted exactly like spllt_factor's, on timing-enabled
+    events of the call -- the completion time of every event the program records.  The times obey
+    the program (events of one stream in order, nothing before what it waited for), and the
+    factor the call leaves behind is the factor of the values it was given (against the oracle)."""
+    A = matgen.nd_like((12, 11, 10), 2)
+    f, val = make_case(A, nb=64, nemin=16)
+    f.factor(val).wait()
+    t = f.timeline(val * 2.0)
+    L = f.program("launches")
+    assert len(t) == len(L) + 1
+    rec = L[:, 7] >= 0
+    assert rec.sum() > 10
+    assert (t[:-1][rec] >= 0).all() and (t[:-1][~rec] == -1).all()
+    assert t[:-1].max() - 1e-3 <= t[-1] < 1e3
+    for st in set(L[:, 6].tolist()):
+        tt = t[:-1][(L[:, 6] == st) & rec]
+        assert (np.diff(tt) >= -2e-3).all(), st          # (event resolution ~1 us)
+    at = {int(L[i, 7]): t[i] for i in range(len(L)) if rec[i]}
+    for i in np.where(rec)[0]:
+        for w in L[i, 8:12]:
+            if w >= 0:
+                assert t[i] >= at[int(w)] - 2e-3, (i, int(w))
+    o, rc = oracle_factor(f, val * 2.0)
+    assert rc == 0
+    assert rel_err(f.get_factor(), o.arena(), lower_mask(f)) <= TOL_L
+    f.close()
+
+
 @pytest.mark.parametrize("kind", ["single-columns", "hand-amalgamated"])
 @pytest.mark.parametrize("gen,nb", [(lambda: matgen.poisson2d(20), 8), (lambda: matgen.nd_like((9, 8, 8), 2), 64),
                                     (lambda: matgen.fe27((6, 5, 5), 3), 96)])
