@@ -115,7 +115,7 @@ def roofline_from_profile(f, val):
     return roof, table, ms
 
 
-PROFILE_DIRS = {"nd24k_like": "nd24k", "poisson3d_128": "p3d128", "serena_like": "serena"}
+PROFILE_DIRS = {"nd24k_like": "nd24k", "poisson3d_128": "p3d128", "serena_like": "serena", "flan_like": "flan"}
 
 
 def attach_pmc(roof, workload):
