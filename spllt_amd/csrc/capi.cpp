@@ -832,6 +832,8 @@ int spllt_hip_profile_in_program(void* fkeep, const double* val, int nnz, float*
 static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int capacity, bool serial) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f || !f->S || !val) return SPLLT_ERROR_PARAMETER;
+  if (f->dead) return SPLLT_ERROR_HIP;
+  (void)do_wait(f);            // a factorization still in flight owns the streams and the events
   if (!f->eng) f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
   if (!f->eng || f->eng->status()) return SPLLT_ERROR_HIP;
   std::vector<float> v;
@@ -845,6 +847,8 @@ static int profile_impl(void* fkeep, const double* val, int nnz, float* ms, int 
 int spllt_hip_timeline(void* fkeep, const double* val, int nnz, float* t_ms, int capacity) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f || !f->S || !val) return SPLLT_ERROR_PARAMETER;
+  if (f->dead) return SPLLT_ERROR_HIP;
+  (void)do_wait(f);            // a factorization still in flight owns the streams and the events
   if (!f->eng) f->eng.reset(new (std::nothrow) Engine(f->S, f->eo));
   if (!f->eng || f->eng->status()) return SPLLT_ERROR_HIP;
   std::vector<float> v;

@@ -878,7 +878,7 @@ def test_timeline_of_the_real_program():
     factor the call leaves behind is the factor of the values it was given (against the oracle)."""
     A = matgen.nd_like((12, 11, 10), 2)
     f, val = make_case(A, nb=64, nemin=16)
-    f.factor(val).wait()
+    f.factor(val)                       # (still in flight: the call drains it first)
     t = f.timeline(val * 2.0)
     L = f.program("launches")
     assert len(t) == len(L) + 1
