@@ -294,6 +294,19 @@ def main():
 
     roof, table, ms = roofline_from_profile(f, val)
     attach_pmc(roof, name)
+    # the real program on the clock (spllt_hip_timeline: its own events, nothing added to the
+    # streams): ms after the value scatter at which the last event of each tree level completed
+    level_done = None
+    try:
+        Lh = f.program("launches")
+        runs = np.array([f.timeline(val) for _ in range(3)])
+        tl = runs[int(np.argmin(runs[:, -1]))]
+        level_done = {"program_end_ms": round(float(tl[-1]), 3),
+                      "level_done_ms": [round(float(max(tl[i] for i in range(len(Lh)) if Lh[i][1] == k and tl[i] >= 0)), 3)
+                                        for k in sorted(set(int(v) for v in Lh[:, 1]) - {-1})
+                                        if any(Lh[i][1] == k and tl[i] >= 0 for i in range(len(Lh)))]}
+    except Exception as e:   # noqa: BLE001 - a diagnostic, never a reason to lose the line
+        level_done = {"error": repr(e)[:200]}
     if args.profile_out:
         Lh = f.program("launches")
         units, tiles = f.program("units"), f.program("tiles")
@@ -388,7 +401,7 @@ def main():
                    "host_submit_ms_per_step": round(float(np.mean(sub_ms)), 3), "analyse_s": round(t_analyse, 2),
                    "dropin_factor_s": round(t_h2d, 4), "L_d2h_s": round(t_d2h, 4),
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
-                   "launches": nlaunch, "kernel_table": table, "check": check,
+                   "launches": nlaunch, "kernel_table": table, "timeline": level_done, "check": check,
                    "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin,
                    "dgemm_reference": dgemm_ref, "configs": extra},
     }
