@@ -241,7 +241,12 @@ def main():
 
     if world > 1:
         from spllt_amd import multigpu
-        out = multigpu.bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world)
+        def roofline_of(f1, v):
+            roof1, _, _ = roofline_from_profile(f1, v)
+            attach_pmc(roof1, name)
+            return roof1
+        out = multigpu.bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world,
+                                         roofline_fn=roofline_of)
         if rank == 0:
             print(json.dumps(out))
         dist.barrier()

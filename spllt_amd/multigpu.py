@@ -231,7 +231,7 @@ def _timed(df, dval, steps, active):
     return float(dt.item())
 
 
-def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
+def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world, roofline_fn=None):
     """bench.py body for N > 1 (strong scaling: one factorization, N GPUs).
 
     `value` is ALWAYS the run that uses all N ranks (partition width = N).  The
@@ -281,6 +281,22 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
         top_flops = float(df.f.sym_info()["flops"]) - own_w.sum()
     if not args.no_check:
         check = _accuracy_gate(df, A, n, rank, w, True)
+    # roofline of the dominant kernel: the partitioned program has no per-launch profile (its
+    # exchange points are collectives), so rank 0 measures the single-GPU program of the SAME
+    # workload, live, after the timed region (the other ranks wait at the next collective)
+    roof = None
+    if rank == 0 and roofline_fn is not None:
+        try:
+            from . import api
+            f1 = api.Factorization(n, ptr, row, nb=nb, nemin=getattr(args, "nemin", 32), prune_tree=False, order=order,
+                                   panel_width=args.panel)
+            f1.factor_dev(dval.data_ptr()).wait()
+            roof = roofline_fn(f1, val)
+            roof["note"] = ("measured on rank 0 with the single-GPU program of the same workload (the partitioned "
+                            "program's exchange points are collectives: no per-launch profile)")
+            f1.close()
+        except Exception as e:   # noqa: BLE001 - a diagnostic, never a reason to lose the line
+            roof = {"error": repr(e)[:200]}
     out = None
     if rank == 0:
         out = {
@@ -296,7 +312,7 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world):
                                        "per finished block-column step" if df.dist_top else
                                        f"subtree partition over all {world} GPUs + one RCCL all-reduce "
                                        "(extend-add) on the engine's stream, replicated top tree")},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "cpu_baseline": None,
             "detail": {"partition_width": w, "width_trials_ms": trial, "distributed_top_tree": df.dist_top,
                        "exchanges": len(df.plan),
                        "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,

@@ -313,6 +313,10 @@ def test_bench_contract_two_ranks_over_gloo(dist_top):
     assert d["value"] > 0 and d["detail"]["partition_width"] == 2
     assert d["detail"]["distributed_top_tree"] == (dist_top == "1")
     assert d["detail"]["check"]["bwd_err"] <= 1e-14
+    # the roofline object of the N > 1 line: rank 0, live, on the single-GPU program of the same workload
+    roof = d["roofline"]
+    assert roof and "error" not in roof, roof
+    assert roof["bound"] == "mfma" and roof["peak"] == 78.6 and 0 < roof["frac"] <= 1 and "single-GPU program" in roof["note"]
 
 
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
