@@ -406,18 +406,19 @@ struct StreamSet {
   int device, reserve, far_on_bulk;
   hipStream_t chain, bulk, far;
   bool in_use;
+  hipStream_t side = nullptr;     // the chain's companion (same priority, no mask): ScheduleOptions::split_next
 };
 std::mutex g_stream_mu;
 std::vector<StreamSet> g_stream_pool;
 }  // namespace
 
 static hipError_t borrow_streams(int device, int reserve, int ncu, bool far_on_bulk, hipStream_t* chain,
-                                 hipStream_t* bulk, hipStream_t* far) {
+                                 hipStream_t* bulk, hipStream_t* far, hipStream_t* side) {
   std::lock_guard<std::mutex> lk(g_stream_mu);
   for (StreamSet& ss : g_stream_pool)
     if (!ss.in_use && ss.device == device && ss.reserve == reserve && ss.far_on_bulk == (int)far_on_bulk) {
       ss.in_use = true;
-      *chain = ss.chain; *bulk = ss.bulk; *far = ss.far;
+      *chain = ss.chain; *bulk = ss.bulk; *far = ss.far; *side = ss.side;
       return hipSuccess;
     }
   int prio_lo = 0, prio_hi = 0;
@@ -437,8 +438,9 @@ static hipError_t borrow_streams(int device, int reserve, int ncu, bool far_on_b
   if ((e = masked_stream(&ss.bulk)) != hipSuccess) return e;
   if (far_on_bulk) ss.far = ss.bulk;
   else if ((e = masked_stream(&ss.far)) != hipSuccess) return e;
+  if ((e = hipStreamCreateWithPriority(&ss.side, hipStreamNonBlocking, prio_hi)) != hipSuccess) return e;
   g_stream_pool.push_back(ss);
-  *chain = ss.chain; *bulk = ss.bulk; *far = ss.far;
+  *chain = ss.chain; *bulk = ss.bulk; *far = ss.far; *side = ss.side;
   return hipSuccess;
 }
 
@@ -496,14 +498,15 @@ void pools_teardown() {
     if (ss.in_use) continue;
     crumb("teardown: streams (query)");
     if (hipStreamQuery(ss.chain) != hipSuccess || hipStreamQuery(ss.bulk) != hipSuccess ||
-        hipStreamQuery(ss.far) != hipSuccess) continue;
+        hipStreamQuery(ss.far) != hipSuccess || (ss.side && hipStreamQuery(ss.side) != hipSuccess)) continue;
     crumb("teardown: streams (destroy chain)");
     (void)hipStreamDestroy(ss.chain);
     crumb("teardown: streams (destroy bulk)");
     (void)hipStreamDestroy(ss.bulk);
     crumb("teardown: streams (destroy far)");
     if (ss.far != ss.bulk) (void)hipStreamDestroy(ss.far);
-    ss.chain = ss.bulk = ss.far = nullptr;
+    if (ss.side) (void)hipStreamDestroy(ss.side);      // (plain priority stream: no CU mask)
+    ss.chain = ss.bulk = ss.far = ss.side = nullptr;
     ss.in_use = true;        // (never handed out again)
   }
   crumb("teardown: events");
@@ -556,9 +559,9 @@ int Engine::upload() {
   // The wide stream only runs when the chains of a level are done -> chain queue.
   crumb("engine: borrowing streams");
   HIPCHK(borrow_streams(device_, reserve, ncu, std::getenv("SPLLT_FAR_ON_BULK") != nullptr, &streams_[ST_CHAIN],
-                        &streams_[ST_BULK], &streams_[ST_FAR]), "stream creation");
+                        &streams_[ST_BULK], &streams_[ST_FAR], &streams_[ST_SIDE]), "stream creation");
   streams_[ST_WIDE] = streams_[ST_CHAIN];
-  streams_[ST_SIDE] = streams_[ST_CHAIN];
+  if (!streams_[ST_SIDE]) streams_[ST_SIDE] = streams_[ST_CHAIN];
   stream_ = streams_[ST_CHAIN];
   crumb("engine: creating events");
   HIPCHK(borrow_events(dag_events_, (size_t)prog_.nevents, device_), "hipEventCreate");

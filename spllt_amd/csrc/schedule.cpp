@@ -704,7 +704,18 @@ struct Builder {
       std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
       std::vector<int> emitted(nodes.size(), 0);
       for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
+      // The update of block column c+1 by block column c sits on the chain stream in front of the
+      // POTRF of c+1's first panel, which needs only its first 64 columns.  split_next: those
+      // columns stay there; the rest (columns 64.., rows 64..) goes to the side stream beside that
+      // POTRF and the solve of the rows below it, and the first in-panel update of c+1 -- the
+      // first launch that touches those columns -- waits for its event (ev_next_rest).
+      const int64_t split_next_env = env_int("SPLLT_SPLIT_NEXT", -1);
+      const bool split_next = la && !partitioned && !det && cb == pw &&
+                              (split_next_env >= 0 ? split_next_env != 0 : opt.split_next);
+      int ev_next_rest = -1;        // recorded by the side launch of the previous step
       for (int c = 0; c < maxnc; ++c) {
+        const int ev_next_rest_in = ev_next_rest;
+        ev_next_rest = -1;
         int maxw = 0;
         for (int s : nodes) {
           const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
@@ -713,15 +724,19 @@ struct Builder {
         const int ng = cdiv(maxw, cb);
         // Latency-bound step (few row blocks below the panels): one fused launch per panel
         bool fuse_c = false, lite_c = false;
-        if (opt.fused_panel && cb == pw && pw <= 64) {
+        auto row_blocks_of_step = [&](int cc) {
           int64_t nt = 0;
           for (int s : nodes) {
             const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-            if (c >= nc) continue;
-            if (!mine(S.node_bcol0[s] + c)) continue;
-            const BlockCol& B = S.bcols[S.node_bcol0[s] + c];
+            if (cc >= nc) continue;
+            if (!mine(S.node_bcol0[s] + cc)) continue;
+            const BlockCol& B = S.bcols[S.node_bcol0[s] + cc];
             nt += std::max(1, cdiv(B.nrow - std::min(pw, B.width), 64));
           }
+          return nt;
+        };
+        if (opt.fused_panel && cb == pw && pw <= 64) {
+          const int64_t nt = row_blocks_of_step(c);
           fuse_c = nt <= fused_max;
           // "lite": more row blocks than the fused launch is worth (every workgroup of it factors
           // the diagonal block itself), but few enough for one round of one workgroup per CU: the
@@ -1011,9 +1026,18 @@ struct Builder {
           // chunk's columns by everything left of them (chain stream: small launches that fit
           // the reserved CUs).  After the last chunk the whole block column updates block
           // column c+1 (chain stream) and c+2.. (bulk stream, beside the chain of c+1).
-          std::vector<UpdUnit> us_n1, us_n2, us_bulk;
-          double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0;
+          std::vector<UpdUnit> us_n1, us_n2, us_bulk, us_side;
+          double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0, fl_side = 0;
           bool to_next_bcol = false;
+          // (the next step must be one of separate launches: a fused panel launch of c+1 would
+          // have to wait for the side launch as a whole)
+          bool split_here = false;
+          if (split_next && c + 1 < maxnc && opt.fused_panel && pw <= 64) {
+            const int64_t nt1 = row_blocks_of_step(c + 1);
+            split_here = nt1 > fused_max && nt1 > lite_max;
+          } else if (split_next && c + 1 < maxnc) {
+            split_here = true;
+          }
           for (int s : nodes) {
             const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
             if (c >= nc) continue;
@@ -1047,9 +1071,18 @@ struct Builder {
                 const BlockCol& D = S.bcols[bd];
                 if (jj == c + 1) {
                   to_next_bcol = true;
-                  UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
-                  us_n1.push_back(n1);
-                  fl_n1 += direct_flops(n1);
+                  if (split_here && D.width > pw && D.nrow > pw) {
+                    UpdUnit n1a = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, pw);
+                    UpdUnit n1b = direct_unit(b, 0, B.width, bd, pw, D.nrow - pw, pw, D.width - pw);
+                    us_n1.push_back(n1a);
+                    fl_n1 += direct_flops(n1a);
+                    us_side.push_back(n1b);
+                    fl_side += direct_flops(n1b);
+                  } else {
+                    UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
+                    us_n1.push_back(n1);
+                    fl_n1 += direct_flops(n1);
+                  }
                 } else {
                   // Trailing updates two source block columns at a time (K = 2 nb: the destination
                   // is read and written once for both, and the update kernel runs 10-15 % faster
@@ -1079,7 +1112,7 @@ struct Builder {
               }
             }
           }
-          P.flops_update += fl_n1 + fl_n2 + fl_bulk;
+          P.flops_update += fl_n1 + fl_n2 + fl_bulk + fl_side;
           if (!us_n1.empty()) {
             Edge e = edge(ST_CHAIN);
             e.lat = 1;
@@ -1088,8 +1121,19 @@ struct Builder {
                 e.wait1 = evB_c1;      // bulk (c-1 -> c+1..) writes the same entries
                 e.wait2 = zev(c + 1);  // and so do the inter-node updates into block column c+1
               }
+              if (g == 0) e.wait0 = ev_next_rest_in;   // the side launch of step c-1 wrote these columns
             }
             emit_gemm(lev, us_n1, fl_n1, true, e);
+          }
+          if (!us_side.empty()) {
+            Edge e = edge(ST_SIDE);
+            e.lat = 1;
+            e.wait0 = evD;             // block column c is final (the last solve of its rows)
+            e.wait1 = evB_c1;
+            e.wait2 = zev(c + 1);
+            ev_next_rest = P.nevents++;
+            e.record = ev_next_rest;
+            emit_gemm(lev, us_side, fl_side, true, e);
           }
           if (!us_n2.empty()) emit_gemm(lev, us_n2, fl_n2, true, edge(ST_CHAIN));   // single-stream program only
           if (g + 1 == ng) {

@@ -271,6 +271,12 @@ struct ScheduleOptions {
   int lite_panel_max = 0;     // steps with more workgroups than fused_panel_max but at most this many: POTRF
                               // launch + ONE k_panel launch for the rows (solve + left-looking update; the
                               // workgroups read the inverted panel instead of factoring it).  0: off
+  bool split_next = false;    // the update of block column c+1 by c: only its first panel's columns on the
+                              // chain stream, the rest on the side stream beside the POTRF / solve of that
+                              // panel (SPLLT_SPLIT_NEXT=1).  Parity-clean (CPU DAG check + emulator, GPU residual)
+                              // and measured: 23.75-23.9 ms against 23.2-23.4 -- the side launch (three quarters
+                              // of the update) outlasts the POTRF + solve it runs beside, and the two event
+                              // hand-overs between the streams cost more than the overlap gives.  Off.
   bool split_tail = false;    // the partly filled last round of a throughput launch is split along K into
                               // several adding workgroups per tile (SPLLT_SPLIT_TAIL=1).  Parity-clean and
                               // measured: single launches alone gain 2-4 % where the tail was long and lose up

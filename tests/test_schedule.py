@@ -339,6 +339,34 @@ def test_launch_tails_split_along_k(gen, nb, pw, nemin, cus, flags, monkeypatch)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
 
+@pytest.mark.parametrize("case", ["nd-32-16", "nd-8-8", "p3d-24-8", "nd-100-8"])
+@pytest.mark.parametrize("flags", [0, 512, 2048, 2, 4096])
+def test_next_block_column_update_split_over_chain_and_side_stream(case, flags, monkeypatch):
+    """ScheduleOptions::split_next (SPLLT_SPLIT_NEXT=1): of the update of block column c+1 by c only
+    the first panel's columns stay on the chain stream; the rest runs on the side stream beside the
+    POTRF / solve of that panel, and the first in-panel update of c+1 waits for it.  The DAG must
+    still order every conflict, the numbers must be the oracle's, the flops the same."""
+    gen, nb, pw = _DAG_GENS[case]
+    A = gen()
+    monkeypatch.setenv("SPLLT_FUSED_PANEL_MAX", "2")     # (test-sized steps would all be fused panel launches)
+    f0, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
+    L0 = f0.program("launches")       # (the host-side program is built when it is asked for)
+    monkeypatch.setenv("SPLLT_SPLIT_NEXT", "1")
+    f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
+    L = f.program("launches")
+    side = L[:, 6] == 3
+    if flags & (2 | 4096):            # single-stream program, deterministic engine: nothing is split
+        assert not side.any()
+    elif case.startswith("nd-") and nb > pw:      # (nodes of several block columns wider than a panel, steps of separate launches)
+        assert side.any() and not (L0[:, 6] == 3).any()
+        assert (L[side, 7] >= 0).all(), "every side launch records the event its columns' first reader waits for"
+    np.testing.assert_allclose(L[:, 5].sum(), L0[:, 5].sum(), rtol=1e-12)
+    bad, *_ = dag_violations(f)
+    assert not bad, bad[:3]
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
 _DAG_GENS = {"nd-32-16": (lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
              "p2d-16-16": (lambda: matgen.poisson2d(40), 16, 16),
              "p3d-24-8": (lambda: matgen.poisson3d(9), 24, 8),
