@@ -169,7 +169,7 @@ class Factorization:
             return raw.view(np.int64).reshape(-1, 6)
         if name == "xbuf_elems":
             return int(raw.view(np.int64)[0])
-        if name in ("chain_block", "scratch_size"):
+        if name in ("chain_block", "scratch_size", "panel_width"):
             return int(raw.view(np.int64)[0])
         if name == "gather_tiles":
             return raw.view(GATHER_TILE_DTYPE)

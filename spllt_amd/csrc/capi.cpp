@@ -793,6 +793,7 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelUnit));
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
   if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }
+  if (k == "panel_width") { int64_t v = P->pw; return raw(&v, sizeof v); }
   if (k == "gather_tiles") return raw(P->gather_tiles.data(), P->gather_tiles.size() * sizeof(GatherTile));
   if (k == "gather_items") return raw(P->gather_items.data(), P->gather_items.size() * sizeof(GatherItem));
   if (k == "scratch_size") { int64_t v = P->scratch_size; return raw(&v, sizeof v); }

@@ -323,7 +323,6 @@ ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
   // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
   // large configurations; the latency-bound bench workload prefers 4096 (24.5 vs 25.0 ms)
   so.tile128_min = lb ? 4096 : 1024;
-  so.tail_cus = 256 - std::max(opt.reserve_cus, 0);   // (gfx950: 256 CUs)
   return so;
 }
 
@@ -724,10 +723,12 @@ Engine::~Engine() {
 void Engine::emit_kernel(const Launch& l, const LaunchSink& sink, bool multi) {
   if (l.kind == L_CHAIN) {
     launch_chain_panel(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
-  } else if (l.kind == L_CHAIN2) {
-    launch_chain2(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.chain_units[(size_t)l.first]);
-  } else if (l.kind == L_TRSM2) {
-    launch_trsm2(sink, d_tiles_ + l.first, l.count, d_units_, d_L_, d_dinv_);
+  } else if (l.kind == L_CHAIN4) {
+    launch_chain_block(sink, d_chain_ + l.first, l.count, d_L_, d_dinv_, d_flag_, prog_.pw,
+                       prog_.chain_units[(size_t)l.first]);
+  } else if (l.kind == L_TRSM4) {
+    launch_trsm_rows(sink, d_tiles_ + l.first, l.count, d_units_, d_L_, d_dinv_, prog_.pw,
+                     (multi && l.stream == ST_CHAIN) ? chain_prio_ : 0);
   } else if (l.kind == L_PANEL) {
     launch_panel(sink, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
   } else if (l.kind == L_GATHER) {

@@ -813,229 +813,6 @@ __global__ __launch_bounds__(256) void k_chain_potrf(const ChainUnit* __restrict
           u.gcol, 8, flag);
 }
 
-// out[16 s + .][16 jb + .] for all four column blocks jb of a 64 x 64 product a b^T (k over 64),
-// for the 4-wave kernels (mma_64 twice)
-__device__ __forceinline__ void mma_64(const double* __restrict__ a, const double* __restrict__ b, int s,
-                                       int jb0, int lane, d4& acc0, d4& acc1);
-__device__ __forceinline__ void mma_64x4(const double* __restrict__ a, const double* __restrict__ b, int s,
-                                         int lane, d4 (&acc)[4]);
-
-// ---------------------------------------------------------------------------
-// One step of the panel chain for a CHAIN BLOCK of two panels (ChainUnit with pn = its width cw,
-// 64 < cw <= 128; narrower blocks take the one-panel path inside): with [L00 0; L10 L11] the
-// Cholesky factor of the cw x cw diagonal block,
-//   L00 = chol(A00), W00 = inv(L00)                    (potrf64)
-//   L10 = A10 W00^T                                     (64 x 64 x 64 on the matrix cores)
-//   L11 = chol(A11 - L10 L10^T), W11 = inv(L11)         (potrf64 on the block updated in LDS)
-//   W10 = -W11 (L10 W00)                                (two more 64^3 products)
-// and [W00 0; W10 W11] goes to the dinv scratch as ONE cw x cw matrix (row stride cw), so that the
-// rows below are solved for both panels by one product (k_update, TRSM mode, N = K = cw) and the
-// left-looking update of the next chain block runs once per 128 columns.  Six dependent launches
-// per 128 columns of the panel chain become three; the ~3 us of in-LDS products replace a TRSM
-// launch, an in-panel update launch and three kernel boundaries.
-// LDS: PotrfShared + two 64 x TLD buffers (L10, W00^T), as k_panel: one workgroup per CU.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chain_potrf2(const ChainUnit* __restrict__ units,
-                                                      double* __restrict__ L,
-                                                      double* __restrict__ dinv,
-                                                      int* __restrict__ flag, const ChainUnit u0) {
-  extern __shared__ __attribute__((aligned(16))) double chain2_smem[];
-  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(chain2_smem);
-  double* U = chain2_smem + sizeof(PotrfShared) / sizeof(double);   // L10
-  double* V = U + 64 * TLD;                                          // W00^T
-  __builtin_amdgcn_s_setprio(3);
-  const ChainUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int cw = u.pn, ld = u.ld;
-  double* A00 = L + u.off + (int64_t)u.c0 * ld + u.c0;
-  double* D00 = dinv + u.winv_off;                // cw x cw, row stride cw
-  const int n0 = min(64, cw), n1 = cw - n0;
-  potrf64(sh, A00, ld, n0, D00, cw, u.gcol, 8, flag);
-  if (n1 <= 0) return;
-  __syncthreads();                                // the tail of potrf64 still read sh.T / sh.X
-  double* A10 = A00 + (int64_t)64 * ld;
-  double* A11 = A10 + 64;
-  double* D10 = D00 + (int64_t)64 * cw;
-  double* D11 = D10 + 64;
-  // V = W00^T; sh.T <- A10 (n1 x 64, zero padded: L00 has gone home)
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    V[c * TLD + r] = sh.X[r * TLD + c];
-  }
-  {
-    // lane = column, the four waves take rows w, w + 4, ...: one wave-instruction reads one row
-    double v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 4 * e + wave;
-      v[e] = A10[(int64_t)(r < n1 ? r : n1 - 1) * ld + lane];
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 4 * e + wave;
-      sh.T[r * TLD + lane] = r < n1 ? v[e] : 0.0;
-    }
-  }
-  __syncthreads();
-  // L10 = A10 W00^T -> U (LDS) and home
-  {
-    d4 acc[4];
-    mma_64x4(sh.T, sh.X, wave, lane, acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lq + 4 * r;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const int j = jb * 16 + lr;
-        U[i * TLD + j] = acc[jb][r];
-        if (i < n1) A10[(int64_t)i * ld + j] = acc[jb][r];
-      }
-    }
-  }
-  __syncthreads();
-  // sh.T <- A11 - L10 L10^T (lower triangle, identity padding): the input of the second POTRF
-  {
-    d4 acc[4];
-    mma_64x4(U, U, wave, lane, acc);
-    double a11[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lq + 4 * r;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const int j = jb * 16 + lr;
-        a11[jb][r] = A11[(int64_t)min(i, n1 - 1) * ld + min(j, n1 - 1)];
-      }
-    }
-    __syncthreads();                              // everybody has read A10's image in sh.T
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lq + 4 * r;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const int j = jb * 16 + lr;
-        sh.T[i * TLD + j] = (i < n1 && j <= i) ? a11[jb][r] - acc[jb][r] : ((i == j) ? 1.0 : 0.0);
-      }
-    }
-  }
-  __syncthreads();
-  potrf64(sh, A11, ld, n1, D11, cw, u.gcol + 64, 8 | 16, flag);
-  __syncthreads();
-  // W10 = -W11 (L10 W00): P = L10 W00 = U V^T (V = W00^T), kept transposed in sh.T (L11 has gone home)
-  {
-    d4 acc[4];
-    mma_64x4(U, V, wave, lane, acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lq + 4 * r;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) sh.T[(jb * 16 + lr) * TLD + i] = acc[jb][r];
-    }
-  }
-  __syncthreads();
-  {
-    d4 acc[4];
-    mma_64x4(sh.X, sh.T, wave, lane, acc);        // W11 P
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lq + 4 * r;
-      if (i >= n1) continue;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) D10[(int64_t)i * cw + jb * 16 + lr] = -acc[jb][r];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The rows below a chain block, solved by its inverse: X = A[rows, block] W^T (a12 spllt_solve_block,
-// kernels_mod:1217-1229, as a product), one workgroup per 64 rows and ALL cw <= 128 columns of the
-// block (UpdTile: unit, ti; the unit a TRSM-mode UpdUnit with N = K = cw).  Latency is what counts
-// here (a launch has a few dozen workgroups and the next chain step waits for it): the whole
-// 64 x cw row block and the three 64 x 64 blocks of W are requested at once, then
-//   X0 = A0 W00^T,  X1 = A0 W10^T + A1 W11^T
-// on the matrix cores from LDS, in place (a workgroup reads all it needs before it writes).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm2(const UpdTile* __restrict__ tiles,
-                                               const UpdUnit* __restrict__ units,
-                                               double* __restrict__ L,
-                                               const double* __restrict__ dinv) {
-  extern __shared__ __attribute__((aligned(16))) double trsm2_smem[];
-  double* A0 = trsm2_smem;
-  double* A1 = A0 + 64 * TLD;
-  double* Wb = A1 + 64 * TLD;
-  double* Wc = Wb + 64 * TLD;
-  __builtin_amdgcn_s_setprio(3);
-  const UpdTile tl = tiles[blockIdx.x];
-  const UpdUnit u = units[tl.unit];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int cw = u.N, ld = u.d_ld, ldw = u.dinv_ld;
-  const int n0 = min(64, cw), n1 = cw - n0;
-  const int r0 = (int)tl.ti * 64, nr = min(64, u.M - r0);
-  double* X = L + u.d_off + (int64_t)(u.d_row0 + r0) * ld + u.d_col0;
-  const double* W = dinv + u.dinv_off;
-  // lane = column, the four waves take rows w, w + 4, ...: one wave-instruction reads one row
-  // (512 contiguous bytes); unconditional loads at clamped addresses, all in flight at once
-  const int cl0 = min(lane, n0 - 1), cl1 = min(lane, max(n1 - 1, 0));
-  double a0[16], a1[16], w00[16], w10[16], w11[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int r = 4 * e + wave;
-    a0[e] = X[(int64_t)(r < nr ? r : nr - 1) * ld + cl0];
-    w00[e] = W[(int64_t)(r < n0 ? r : n0 - 1) * ldw + cl0];
-  }
-  if (n1 > 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 4 * e + wave;
-      const double* wr = W + (int64_t)(64 + (r < n1 ? r : n1 - 1)) * ldw;
-      a1[e] = X[(int64_t)(r < nr ? r : nr - 1) * ld + 64 + cl1];
-      w10[e] = wr[lane];
-      w11[e] = wr[64 + cl1];
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int r = 4 * e + wave;
-    A0[r * TLD + lane] = (r < nr && lane < n0) ? a0[e] : 0.0;
-    Wb[r * TLD + lane] = (r < n0 && lane < n0) ? w00[e] : 0.0;
-  }
-  if (n1 > 0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 4 * e + wave;
-      A1[r * TLD + lane] = (r < nr && lane < n1) ? a1[e] : 0.0;
-      Wc[r * TLD + lane] = r < n1 ? w10[e] : 0.0;
-    }
-  }
-  __syncthreads();
-  d4 x0[4], x1[4];
-  mma_64x4(A0, Wb, wave, lane, x0);                   // A0 W00^T
-  if (n1 > 0) {
-    mma_64x4(A0, Wc, wave, lane, x1);                 // A0 W10^T
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 4 * e + wave;
-      Wb[r * TLD + lane] = (r < n1 && lane < n1) ? w11[e] : 0.0;
-    }
-    __syncthreads();
-    mma_64(A1, Wb, wave, 0, lane, x1[0], x1[1]);      // + A1 W11^T
-    mma_64(A1, Wb, wave, 2, lane, x1[2], x1[3]);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = wave * 16 + lq + 4 * r;
-    if (i >= nr) continue;
-    double* xr = X + (int64_t)i * ld;
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      const int j = jb * 16 + lr;
-      if (j < n0) xr[j] = x0[jb][r];
-      if (j < n1) xr[64 + j] = x1[jb][r];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // One whole panel step of a block column in ONE launch (PanelUnit, tiles = 64-row blocks of
 // the rows below the panel), for the latency-bound levels of the tree: every workgroup
@@ -1264,6 +1041,247 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
     double* crow = A + (int64_t)(r0 + (i < nr ? i : nr - 1)) * ld + cn;
     if (ok0[r]) crow[jb0 * 16 + lr] = c0v[r] - m0[r];
     if (ok1[r]) crow[jb0 * 16 + 16 + lr] = c1v[r] - m1[r];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One step of the panel chain for a CHAIN BLOCK of up to four panels (ChainUnit with pn = its
+// width cw <= 4 pw), one workgroup: the whole cw x cw diagonal block of a block column is
+// factored here, panel by panel, right-looking, with nothing but this workgroup's barriers
+// between the steps (a11 spllt_factor_diag_block, kernels_mod:1168-1189, on the diagonal block):
+//   for p = 0 .. np-1:   L_pp = chol(A_pp), W_pp = inv(L_pp)      (potrf64, waves 0-3)
+//                        L_ip = A_ip W_pp^T            i > p     (64^3 products, all waves)
+//                        A_ij -= L_ip L_jp^T           i >= j > p
+// The blocks below the current panel are staged in LDS (at most three: two buffers behind
+// PotrfShared and sh.T, which is free between two factorizations); the trailing blocks stay
+// where they are -- the arena, 512 KB at most, in L2 -- read and written by this workgroup only
+// (its waves share the CU's vector L1; a barrier behind the stores orders them).  The inverses
+// stay per panel (W_pp: what k_trsm_rows and the solve phase read).
+// Why: per 256 columns the chain stream carried 4 x (POTRF, TRSM, in-panel update) = 12 dependent
+// launches; with this kernel and k_trsm_rows it carries two.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPanelThreads) void k_chain_block(const ChainUnit* __restrict__ units,
+                                                               double* __restrict__ L,
+                                                               double* __restrict__ dinv,
+                                                               int* __restrict__ flag, int pw,
+                                                               const ChainUnit u0) {
+  extern __shared__ __attribute__((aligned(16))) double cblk_smem[];
+  PotrfShared& sh = *reinterpret_cast<PotrfShared*>(cblk_smem);
+  __builtin_amdgcn_s_setprio(3);
+  const ChainUnit u = blockIdx.x == 0 ? u0 : units[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int s = wave >> 1, jb0 = (wave & 1) * 2;   // this wave's 16-row strip and two 16-column blocks
+  const int cw = u.pn, ld = u.ld;
+  const int np = (cw + pw - 1) / pw;
+  double* A = L + u.off + (int64_t)u.c0 * ld + u.c0;   // entry (0, 0) of the diagonal block
+  double* W = dinv + u.winv_off;                        // slot of the block's first panel; panel p: + p pw^2
+  for (int p = 0; p < np; ++p) {
+    const int n_p = min(pw, cw - p * pw);
+    potrf64(sh, A + (int64_t)(p * pw) * ld + p * pw, ld, n_p, W + (int64_t)p * pw * pw, n_p, u.gcol + p * pw, 8,
+            flag);
+    __syncthreads();                                    // (the tail of potrf64 still read sh.T / sh.X)
+    const int nbel = np - 1 - p;                        // blocks below this panel (<= 3)
+    if (nbel == 0) break;
+    // (offsets, not pointers: a select between LDS pointers goes through generic pointers, and this
+    // compiler then emits a compare against src_shared_base that its own verifier rejects)
+    constexpr int kPaOff = (int)(sizeof(PotrfShared) / sizeof(double));
+    constexpr int kTOff = (int)(offsetof(PotrfShared, T) / sizeof(double));
+    auto pbuf = [&](int q) { return cblk_smem + (q == 0 ? kPaOff : (q == 1 ? kPaOff + 64 * TLD : kTOff)); };
+    // ---- L_ip = A_ip W_pp^T, into LDS (operands of the updates) and home ------------------
+#pragma unroll 1
+    for (int q = 0; q < nbel; ++q) {
+      const int i = p + 1 + q, n_i = min(pw, cw - i * pw);
+      stage_block(pbuf(q), A + (int64_t)(i * pw) * ld + p * pw, ld, n_i, n_p, tid);
+    }
+    __syncthreads();
+    // (runtime loops, one block at a time: unrolled, the operand fragments of all blocks are
+    // requested at once and the kernel spills)
+#pragma unroll 1
+    for (int q = 0; q < nbel; ++q) {
+      const int i = p + 1 + q, n_i = min(pw, cw - i * pw);
+      double* Pq = pbuf(q);
+      d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+      mma_64(Pq, sh.X, s, jb0, lane, x0, x1);
+      __syncthreads();                                  // everybody has read the A_ip image
+      double* dst = A + (int64_t)(i * pw) * ld + p * pw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s * 16 + lq + 4 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int col = (jb0 + h) * 16 + lr;
+          const double v = (row < n_i && col < n_p) ? (h ? x1[r] : x0[r]) : 0.0;   // padding: exact zeros
+          Pq[row * TLD + col] = v;
+          if (row < n_i && col < n_p) dst[(int64_t)row * ld + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- A_ij -= L_ip L_jp^T, i >= j > p: the destination entries of the next block are
+    // requested before the product of the current one ---------------------------------------
+    {
+      d4 c0v = {0.0, 0.0, 0.0, 0.0}, c1v = {0.0, 0.0, 0.0, 0.0}, n0v = c0v, n1v = c0v;
+      auto cload = [&](int a, int b, d4& v0, d4& v1) {
+        const int i = p + 1 + a, j = p + 1 + b;
+        const int n_i = min(pw, cw - i * pw), n_j = min(pw, cw - j * pw);
+        const double* C = A + (int64_t)(i * pw) * ld + j * pw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = s * 16 + lq + 4 * r;
+          const double* crow = C + (int64_t)(row < n_i ? row : n_i - 1) * ld;
+          const int ca = jb0 * 16 + lr, cb2 = ca + 16;
+          v0[r] = crow[ca < n_j ? ca : n_j - 1];
+          v1[r] = crow[cb2 < n_j ? cb2 : n_j - 1];
+        }
+      };
+      cload(0, 0, c0v, c1v);
+      // the blocks (a, b), b <= a < nbel, row by row
+      int a = 0, b = 0;
+      const int nupd = nbel * (nbel + 1) / 2;
+#pragma unroll 1
+      for (int t = 0; t < nupd; ++t) {
+        const int a2 = b < a ? a : a + 1, b2 = b < a ? b + 1 : 0;
+        if (t + 1 < nupd) cload(a2, b2, n0v, n1v);
+        const int i = p + 1 + a, j = p + 1 + b;
+        const int n_i = min(pw, cw - i * pw), n_j = min(pw, cw - j * pw);
+        d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+        mma_64(pbuf(a), pbuf(b), s, jb0, lane, m0, m1);
+        double* C = A + (int64_t)(i * pw) * ld + j * pw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = s * 16 + lq + 4 * r;
+          const int ca = jb0 * 16 + lr, cb2 = ca + 16;
+          if (row >= n_i) continue;
+          // (diagonal blocks: the lower triangle only -- what lies above it is never written)
+          if (ca < n_j && (a != b || ca <= row)) C[(int64_t)row * ld + ca] = c0v[r] - m0[r];
+          if (cb2 < n_j && (a != b || cb2 <= row)) C[(int64_t)row * ld + cb2] = c1v[r] - m1[r];
+        }
+        c0v = n0v;
+        c1v = n1v;
+        a = a2;
+        b = b2;
+      }
+    }
+    // the next factorization reads A_{p+1,p+1} from the arena, the next solves the rest
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The rows below a chain block, solved against its factored diagonal block (a12 spllt_solve_block,
+// kernels_mod:1217-1229, for all panels of the block at once): one workgroup per 32 rows and ALL
+// cw <= 4 pw columns of the block (UpdTile: unit, ti; the unit a TRSM-mode UpdUnit with N = cw),
+//   X_p = (A_p - sum_{q<p} X_q L_pq^T) W_pp^T,   p = 0 .. np-1,
+// ten 32 x 64 x 64 products for a 256-wide block, every operand block (L_pq from the arena, W_pp
+// from the dinv scratch: both written by k_chain_block) requested one product ahead, the X_q kept
+// in LDS as operands.  In place: a workgroup reads its rows before it writes them and nobody
+// else touches them.  Replaces, per 256 columns, four TRSM launches (K = 64: 151 launches at 3
+// TFLOP/s on the bench workload) and three in-panel update launches on the chain stream.
+// ---------------------------------------------------------------------------
+constexpr int kTrsmRows = 32;
+__global__ __launch_bounds__(256) void k_trsm_rows(const UpdTile* __restrict__ tiles,
+                                                   const UpdUnit* __restrict__ units,
+                                                   double* __restrict__ L,
+                                                   const double* __restrict__ dinv, int pw, int prio) {
+  extern __shared__ __attribute__((aligned(16))) double trows_smem[];
+  double* XS = trows_smem;                          // X_0 .. X_2 as operands: [3][32][TLD]
+  double* G = XS + 3 * kTrsmRows * TLD;             // A_p - sum X_q L_pq^T as an operand
+  double* Bst = G + kTrsmRows * TLD;                // [2][64][TLD]: L_pq / W_pp
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const UpdTile tl = tiles[blockIdx.x];
+  const UpdUnit u = units[tl.unit];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int s = wave >> 1, jb0 = (wave & 1) * 2;
+  const int cw = u.N, ld = u.d_ld;
+  const int np = (cw + pw - 1) / pw;
+  const int r0 = (int)tl.ti * kTrsmRows, nr = min(kTrsmRows, u.M - r0);
+  double* X = L + u.d_off + (int64_t)(u.d_row0 + r0) * ld + u.d_col0;
+  const double* Ld = L + u.d_off + (int64_t)u.d_col0 * ld + u.d_col0;    // the factored diagonal block
+  const double* W = dinv + u.dinv_off;
+  // this workgroup's rows, in accumulator layout, all panels at once
+  double av[4][2][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int n_p = min(pw, cw - p * pw);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s * 16 + lq + 4 * r, col = (jb0 + h) * 16 + lr;
+        double v = 0.0;
+        if (p < np) v = X[(int64_t)(row < nr ? row : nr - 1) * ld + p * pw + (col < n_p ? col : n_p - 1)];
+        av[p][h][r] = (p < np && row < nr && col < n_p) ? v : 0.0;
+      }
+  }
+  // operand blocks, one product ahead: 64 x 64 through 16 registers per thread
+  const int fr = tid >> 3, fc = tid & 7;
+  double bv[16];
+  int cur_nrow = 0, cur_ncol = 0;
+  auto fetch = [&](int p, int q) {
+    const int n_p = min(pw, cw - p * pw);
+    const double* src;
+    int64_t l;
+    if (q == p) { src = W + (int64_t)p * pw * pw; l = n_p; cur_ncol = n_p; }
+    else { src = Ld + (int64_t)(p * pw) * ld + q * pw; l = ld; cur_ncol = pw; }
+    cur_nrow = n_p;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = fr + 32 * h;
+      const double* row = src + (int64_t)(r < cur_nrow ? r : cur_nrow - 1) * l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[8 * h + e] = row[fc + 8 * e < cur_ncol ? fc + 8 * e : cur_ncol - 1];
+    }
+  };
+  fetch(0, 0);
+  int t = 0;
+  for (int p = 0; p < np; ++p) {
+    const int n_p = min(pw, cw - p * pw);
+    d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q <= p; ++q, ++t) {
+      double* B = Bst + (t & 1) * (64 * TLD);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = fr + 32 * h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          B[r * TLD + fc + 8 * e] = (r < cur_nrow && fc + 8 * e < cur_ncol) ? bv[8 * h + e] : 0.0;
+      }
+      if (q == p) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = s * 16 + lq + 4 * r, col = (jb0 + h) * 16 + lr;
+            double a = 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) a = pp == p ? av[pp][h][r] : a;
+            G[row * TLD + col] = a - (h ? m1[r] : m0[r]);
+          }
+      }
+      // the next operand block flies during this product
+      if (q < p) fetch(p, q + 1);
+      else if (p + 1 < np) fetch(p + 1, 0);
+      __syncthreads();
+      if (q < p) {
+        mma_64(XS + q * (kTrsmRows * TLD), B, s, jb0, lane, m0, m1);
+      } else {
+        d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+        mma_64(G, B, s, jb0, lane, x0, x1);
+        double* Xp = XS + (p < 3 ? p : 0) * (kTrsmRows * TLD);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = s * 16 + lq + 4 * r;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int col = (jb0 + h) * 16 + lr;
+            const double v = col < n_p ? (h ? x1[r] : x0[r]) : 0.0;     // padding columns: exact zeros
+            if (p + 1 < np) Xp[row * TLD + col] = v;
+            if (row < nr && col < n_p) X[(int64_t)row * ld + p * pw + col] = v;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -1849,19 +1867,14 @@ __device__ __forceinline__ void update_dma_body(const UpdTile* __restrict__ tile
 }
 
 
-// the two instantiations, with the register budget (second launch bound = waves per SIMD) that
-// keeps 2 (128-tile) / 5 (64-tile) workgroups per CU resident
+// the 128-tile instantiation, with the register budget (second launch bound = waves per SIMD) that
+// keeps 2 workgroups per CU resident.  (A 64-tile instantiation lost to the register-staged 64-tile
+// at every K -- 46.9 vs 51.8 TFLOP/s at K = 256 -- and was removed in round 4.)
 __global__ __launch_bounds__(512, 4) void k_update_dma128(
     const UpdTile* __restrict__ tiles, const UpdUnit* __restrict__ units, const int64_t* __restrict__ bc_off,
     const int* __restrict__ bc_w, double* __restrict__ L, const int* __restrict__ relpos,
     const int* __restrict__ rlist, const double* __restrict__ dinv, int prio) {
   update_dma_body<128, 4, 2>(tiles, units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
-}
-__global__ __launch_bounds__(256, 5) void k_update_dma64(
-    const UpdTile* __restrict__ tiles, const UpdUnit* __restrict__ units, const int64_t* __restrict__ bc_off,
-    const int* __restrict__ bc_w, double* __restrict__ L, const int* __restrict__ relpos,
-    const int* __restrict__ rlist, const double* __restrict__ dinv, int prio) {
-  update_dma_body<64, 2, 2>(tiles, units, bc_off, bc_w, L, relpos, rlist, dinv, prio);
 }
 
 // ---------------------------------------------------------------------------
@@ -2254,32 +2267,32 @@ void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t co
   emit(st, k_chain_potrf, dim3((unsigned)count), dim3(256), 0, units, L, dinv, flag, unit0);
 }
 
-void launch_chain2(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
-                   int* flag, const ChainUnit& unit0) {
+void launch_chain_block(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+                        int* flag, int pw, const ChainUnit& unit0) {
   if (count <= 0) return;
   const unsigned lds = (unsigned)(sizeof(PotrfShared) + sizeof(double) * 2 * 64 * TLD);
   thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev != attr_dev) {
-    (void)hipFuncSetAttribute((const void*)k_chain_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_chain_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_dev = dev;
   }
-  emit(st, k_chain_potrf2, dim3((unsigned)count), dim3(256), lds, units, L, dinv, flag, unit0);
+  emit(st, k_chain_block, dim3((unsigned)count), dim3(kPanelThreads), lds, units, L, dinv, flag, pw, unit0);
 }
 
-void launch_trsm2(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
-                  const double* dinv) {
+void launch_trsm_rows(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
+                      const double* dinv, int pw, int prio) {
   if (count <= 0) return;
-  const unsigned lds = (unsigned)(sizeof(double) * 4 * 64 * TLD);
+  const unsigned lds = (unsigned)(sizeof(double) * (4 * kTrsmRows + 2 * 64) * TLD);
   thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev != attr_dev) {
-    (void)hipFuncSetAttribute((const void*)k_trsm2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_trsm_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_dev = dev;
   }
-  emit(st, k_trsm2, dim3((unsigned)count), dim3(256), lds, tiles, units, L, dinv);
+  emit(st, k_trsm_rows, dim3((unsigned)count), dim3(256), lds, tiles, units, L, dinv, pw, prio);
 }
 
 void launch_panel(const LaunchSink& st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,
@@ -2439,31 +2452,23 @@ void launch_update(const LaunchSink& st, int tile, const UpdTile* tiles, int64_t
       attr_dev = dev;
     }
   }
-  // operand tiles straight into LDS (k_update_dma) for the 128- and 64-tiles; SPLLT_UPD_DMA=0: the
-  // register-staged kernels
+  // operand tiles straight into LDS (k_update_dma128) for the 128-tiles; SPLLT_UPD_DMA=0: the
+  // register-staged kernel
   static const bool use_dma = [] {
     const char* e = std::getenv("SPLLT_UPD_DMA");
     return !(e && std::atoi(e) == 0);
   }();
-  // (the 64-tile loses with it: 96 registers for 5 waves per SIMD cost spills, 47.3 vs 51.8 TFLOP/s at K = 256;
-  // SPLLT_UPD_DMA=2 selects it all the same)
-  static const bool dma64 = [] { const char* e = std::getenv("SPLLT_UPD_DMA"); return e && std::atoi(e) == 2; }();
-  if (use_dma && allow_dma && (tile == 128 || (tile == 64 && dma64))) {
+  if (use_dma && allow_dma && tile == 128) {
     const unsigned lds = (unsigned)(2 * 2 * tile * 128) + (lds_pad > 0 ? (unsigned)lds_pad : 0u);
     thread_local int attr_dev2 = -1;
     int dev2 = 0;
     (void)hipGetDevice(&dev2);
     if (dev2 != attr_dev2) {
       (void)hipFuncSetAttribute((const void*)k_update_dma128, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_update_dma64, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_dev2 = dev2;
     }
-    if (tile == 128)
-      emit(st, k_update_dma128, dim3((unsigned)count), dim3(512), lds, tiles, units, bc_off, bc_w, L, relpos, rlist,
-           dinv, prio);
-    else
-      emit(st, k_update_dma64, dim3((unsigned)count), dim3(256), lds, tiles, units, bc_off, bc_w, L, relpos, rlist,
-           dinv, prio);
+    emit(st, k_update_dma128, dim3((unsigned)count), dim3(512), lds, tiles, units, bc_off, bc_w, L, relpos, rlist,
+         dinv, prio);
     return;
   }
   if (tile == 128)

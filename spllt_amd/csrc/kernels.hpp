@@ -30,12 +30,13 @@ void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double*
 // one step of the panel chain per workgroup (ChainUnit): POTRF of the panel + its inverse
 void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
                         int* flag, const ChainUnit& unit0);
-// one chain block of two panels per workgroup (ChainUnit, pn = its width <= 128): factor + full inverse
-void launch_chain2(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
-                   int* flag, const ChainUnit& unit0);
-// the rows below a chain block solved by its inverse, 64 rows x all columns per workgroup (tiles: unit, ti)
-void launch_trsm2(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
-                  const double* dinv);
+// one chain block of up to four panels per workgroup (ChainUnit, pn = its width <= 4 pw): the whole
+// diagonal block factored, the panels' inverses emitted
+void launch_chain_block(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
+                        int* flag, int pw, const ChainUnit& unit0);
+// the rows below a chain block solved against it, 32 rows x all columns per workgroup (tiles: unit, ti)
+void launch_trsm_rows(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
+                      const double* dinv, int pw, int prio);
 // one whole panel step per launch (PanelUnit; tiles: unit, ti = 64-row block below the panel)
 // counters: two zero-initialised ints per panel unit (left zero again by the launch)
 void launch_panel(const LaunchSink& st, const UpdTile* tiles, int64_t count, const PanelUnit* units, double* L,

@@ -84,10 +84,10 @@ struct OpsBatch {
           launch_potrf(st, d_potrf + l.first, l.count, base, d_dinv, d_flag, P.potrf_units[(size_t)l.first]);
         else if (l.kind == L_CHAIN)
           launch_chain_panel(st, d_chain + l.first, l.count, base, d_dinv, d_flag, P.chain_units[(size_t)l.first]);
-        else if (l.kind == L_CHAIN2)
-          launch_chain2(st, d_chain + l.first, l.count, base, d_dinv, d_flag, P.chain_units[(size_t)l.first]);
-        else if (l.kind == L_TRSM2)
-          launch_trsm2(st, d_tiles + l.first, l.count, d_units, base, d_dinv);
+        else if (l.kind == L_CHAIN4)
+          launch_chain_block(st, d_chain + l.first, l.count, base, d_dinv, d_flag, P.pw, P.chain_units[(size_t)l.first]);
+        else if (l.kind == L_TRSM4)
+          launch_trsm_rows(st, d_tiles + l.first, l.count, d_units, base, d_dinv, P.pw, 0);
         else if (l.kind == L_PANEL)
           launch_panel(st, d_tiles + l.first, l.count, d_panel, base, d_dinv, d_pcnt, d_flag);
         else

@@ -184,103 +184,6 @@ struct Builder {
     };
     xcd_order(t128, 128);
     xcd_order(t64, 64);
-    // The last, partly filled round of a throughput launch, split along K.  A launch of n tiles
-    // runs in rounds of `slots` workgroups (2 per CU for the 128-tile, 4 for the 64-tile); the
-    // r = n mod slots tiles of the last round occupy r / slots of the chip for a whole tile time
-    // (measured, scripts/update_bench.hip over M: 5.0 rounds of 128-tiles at K = 512 run at 64.7
-    // TFLOP/s, 5.125 rounds at 60.0; the inter-node launches of the bench workload are 2-8 rounds
-    // long).  Inter-node and trailing updates ADD into their destination, so a tile's K range can
-    // be dealt to several workgroups that each add their part (atomically): the last r tiles
-    // become p r workgroups with 1/p of the K extent each, p = slots / r (at most 4, at least 64
-    // columns per piece; 8 workgroups of 32-tiles per CU).  A piece is a unit of its own: the K segments [s0, s1) of the tile's
-    // unit, or a column window of its single segment.
-    const int64_t split_env = env_int("SPLLT_SPLIT_TAIL", -1);      // (read per program: tests switch it)
-    const bool split_on = split_env >= 0 ? split_env != 0 : opt.split_tail;
-    const int64_t tail_cus = env_int("SPLLT_TAIL_CUS", opt.tail_cus);
-    const int min_k = (int)std::max<int64_t>(env_int("SPLLT_SPLIT_MINK", 64), 1);   // columns per piece, at least
-    auto split_tail = [&](std::vector<UpdTile>& tv, int T) {
-      if (!split_on || !throughput || opt.deterministic) return;
-      const size_t slots = (size_t)(T == 128 ? 2 : (T == 64 ? 4 : 8)) * (size_t)std::max<int64_t>(tail_cus, 1);
-      if (tv.size() < slots) return;
-      const size_t r = tv.size() % slots;
-      if (r == 0 || r * 10 >= slots * 7) return;
-      const int p = (int)std::min<size_t>(slots / r, 4);
-      if (p < 2) return;
-      std::vector<UpdTile> tail(tv.end() - (long)r, tv.end());
-      tv.resize(tv.size() - r);
-      std::vector<std::pair<int, std::vector<int>>> done;   // unit -> its pieces (few units per tail)
-      auto pieces_of = [&](int uid) -> const std::vector<int>& {
-        for (const auto& d : done)
-          if (d.first == uid) return d.second;
-        std::vector<int> ids;
-        const UpdUnit u = P.units[(size_t)uid];
-        std::vector<UpdUnit> pcs;
-        if (u.mode == MODE_SCATTER || u.mode == MODE_DIRECT) {
-          if (u.nseg >= 2) {
-            // groups of consecutive K segments of about equal width
-            const int g = std::min(p, u.nseg);
-            int64_t total = 0;
-            for (int sg = 0; sg < u.nseg; ++sg) total += S.bcols[u.src_bcol0 + sg].width;
-            int s0 = 0;
-            int64_t acc = 0;
-            for (int i = 0; i < g && s0 < u.nseg; ++i) {
-              int s1 = s0;
-              const int64_t want = total * (i + 1) / g;
-              do acc += S.bcols[u.src_bcol0 + s1++].width; while (s1 < u.nseg && acc < want && u.nseg - s1 > g - 1 - i);
-              if (i == g - 1) s1 = u.nseg;
-              UpdUnit q = u;
-              q.src_bcol0 = u.src_bcol0 + s0;
-              q.nseg = s1 - s0;
-              q.seg_r0 = u.seg_r0 + s0 * u.seg_stride;
-              if (u.b_bcol0 >= 0) {
-                q.b_bcol0 = u.b_bcol0 + s0;
-                q.b_seg_r0 = u.b_seg_r0 + s0 * u.seg_stride;
-              }
-              q.k0 = 0;
-              q.klen = -1;
-              pcs.push_back(q);
-              s0 = s1;
-            }
-          } else {
-            const int kbeg = u.klen >= 0 ? u.k0 : 0;
-            const int K = u.klen >= 0 ? u.klen : S.bcols[u.src_bcol0].width;
-            const int g = std::min(p, K / min_k);
-            if (g >= 2) {
-              const int step = ((K + g - 1) / g + 15) / 16 * 16;
-              for (int k = 0; k < K; k += step) {
-                UpdUnit q = u;
-                q.k0 = kbeg + k;
-                q.klen = std::min(step, K - k);
-                pcs.push_back(q);
-              }
-            }
-          }
-        }
-        if (pcs.size() < 2) {
-          ids.push_back(uid);
-        } else {
-          for (UpdUnit& q : pcs) {
-            if (q.mode == MODE_DIRECT) q.atomic = 1;   // several workgroups add into the tile now
-            q.a_w = S.bcols[q.src_bcol0].width;
-            q.a_off = S.bcols[q.src_bcol0].off;
-            ids.push_back((int)P.units.size());
-            P.units.push_back(q);
-            us.push_back(q);
-          }
-        }
-        done.push_back({uid, ids});
-        return done.back().second;
-      };
-      for (const UpdTile& t : tail)
-        for (int id : pieces_of(t.unit)) {
-          UpdTile q = t;
-          q.unit = id;
-          tv.push_back(q);
-        }
-    };
-    split_tail(t128, 128);
-    split_tail(t64, 64);
-    split_tail(t32, 32);
     // useful flops of ONE tile of a unit, the convention of the whole program (and of the
     // reference's symbolic count): 2 K per entry the tile really computes for the destination
     // (entries above the diagonal of a unit that straddles it do not count); TRSM: the
@@ -565,14 +468,14 @@ struct Builder {
 
   void run() {
     P.pw = pw;
-    // chain block = two panels, factored (and inverted) by ONE workgroup of k_chain_potrf2; the
-    // rows below are solved for both panels by one product with the 2 pw x 2 pw inverse and the
-    // left-looking update runs once per chain block: three dependent launches per 128 columns
-    // instead of six.  (chain2 off: one panel per chain step, the round-2 shape.  Round 2's wider
-    // "chain blocks" walked by a chain kernel that also solved and updated rows are gone.)
-    const bool chain2 = env_int("SPLLT_CHAIN2", opt.chain2 ? 1 : 0) != 0;
-    const int cb = chain2 ? 2 * pw : pw;
-    const int pq = cb;                       // columns one chain step factors
+    // A block-column step whose block columns are wider than one panel runs in CHAIN BLOCKS of up
+    // to four panels: the whole diagonal block of the chain block is factored by ONE workgroup
+    // (L_CHAIN4, k_chain_block) and the rows below are solved against it by one launch (L_TRSM4,
+    // k_trsm_rows) -- two dependent launches per 4 pw columns of the panel chain instead of twelve
+    // (POTRF, TRSM, in-panel update per panel).  chain4 off: one panel per chain step.  The layout
+    // of the inverses is per panel either way (cb = pw).
+    const bool chain4 = env_int("SPLLT_CHAIN4", opt.chain4 ? 1 : 0) != 0;
+    const int cb = pw;                       // layout of the dinv slots: one pn x pn inverse per panel
     P.cb = cb;
     const int nn = S.nnodes;
     int maxlevel = -1;
@@ -591,9 +494,8 @@ struct Builder {
       P.dinv_size = o;
     }
     const int64_t fused_max = env_int("SPLLT_FUSED_PANEL_MAX", opt.fused_panel_max);
-    const int64_t lite_max = env_int("SPLLT_LITE_PANEL_MAX", opt.lite_panel_max);
     int super_panel = (int)env_int("SPLLT_SUPER_PANEL", opt.super_panel);
-    if (super_panel % cb != 0) super_panel = 0;            // (a multiple of the panel width, or off)
+    if (super_panel % (4 * pw) != 0) super_panel = 0;      // (a multiple of the chain block, or off)
 
     const bool la = opt.lookahead;
     const bool det_all = opt.deterministic;
@@ -704,26 +606,19 @@ struct Builder {
       std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
       std::vector<int> emitted(nodes.size(), 0);
       for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
-      // The update of block column c+1 by block column c sits on the chain stream in front of the
-      // POTRF of c+1's first panel, which needs only its first 64 columns.  split_next: those
-      // columns stay there; the rest (columns 64.., rows 64..) goes to the side stream beside that
-      // POTRF and the solve of the rows below it, and the first in-panel update of c+1 -- the
-      // first launch that touches those columns -- waits for its event (ev_next_rest).
-      const int64_t split_next_env = env_int("SPLLT_SPLIT_NEXT", -1);
-      const bool split_next = la && !partitioned && !det && cb == pw &&
-                              (split_next_env >= 0 ? split_next_env != 0 : opt.split_next);
-      int ev_next_rest = -1;        // recorded by the side launch of the previous step
       for (int c = 0; c < maxnc; ++c) {
-        const int ev_next_rest_in = ev_next_rest;
-        ev_next_rest = -1;
         int maxw = 0;
         for (int s : nodes) {
           const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
           if (c < nc) maxw = std::max(maxw, S.bcols[S.node_bcol0[s] + c].width);
         }
-        const int ng = cdiv(maxw, cb);
+        // chain blocks of up to four panels for a step that has block columns of several panels
+        // (a step of one-panel block columns is what it always was: one fused launch, or POTRF + TRSM)
+        const bool blk4 = chain4 && maxw > pw;
+        const int cstep = blk4 ? 4 * pw : pw;    // columns one chunk of the step covers
+        const int ng = cdiv(maxw, cstep);
         // Latency-bound step (few row blocks below the panels): one fused launch per panel
-        bool fuse_c = false, lite_c = false;
+        bool fuse_c = false;
         auto row_blocks_of_step = [&](int cc) {
           int64_t nt = 0;
           for (int s : nodes) {
@@ -735,27 +630,11 @@ struct Builder {
           }
           return nt;
         };
-        if (opt.fused_panel && cb == pw && pw <= 64) {
-          const int64_t nt = row_blocks_of_step(c);
-          fuse_c = nt <= fused_max;
-          // "lite": more row blocks than the fused launch is worth (every workgroup of it factors
-          // the diagonal block itself), but few enough for one round of one workgroup per CU: the
-          // POTRF stays a launch of its own and ONE k_panel launch (PanelUnit flag 1: the panel is
-          // factored, its inverse is in the dinv scratch) does the solve of all rows and the
-          // left-looking update of the next panel -- two launches per panel instead of three
-          lite_c = !fuse_c && !dist2 && nt <= lite_max;
-        }
+        if (opt.fused_panel && !blk4 && pw <= 64) fuse_c = row_blocks_of_step(c) <= fused_max;
         const int evB_c2 = (la && c >= 2) ? evB_hist[c - 2] : -1;   // bulk (c-2 -> c..)
         const int evB_c1 = (la && c >= 1) ? evB_hist[c - 1] : -1;   // bulk (c-1 -> c+1..)
         for (int g = 0; g < ng; ++g) {
-          const int cs = g * cb;
-          int maxq = 0;
-          for (int s : nodes) {
-            const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-            if (c >= nc) continue;
-            const int w = S.bcols[S.node_bcol0[s] + c].width;
-            if (cs < w) maxq = std::max(maxq, cdiv(std::min(cb, w - cs), pq));
-          }
+          const int cs = g * cstep;
           // "block column final" event: only after the last chunk of the step (what the bulk / far
           // streams and the level end wait for); it rides on the chunk's last chain-stream launch --
           // a launch of its own per panel (an event record behind every kernel of the chain)
@@ -765,45 +644,7 @@ struct Builder {
             evD = P.nevents++;
             evD_last = evD;
           }
-          if (lite_c) {
-            // POTRF of the panel, one workgroup per node (as in the unfused steps below)
-            Launch L;
-            L.kind = L_CHAIN;
-            L.level = lev;
-            L.first = (int64_t)P.chain_units.size();
-            L.tile = 0;
-            double fl = 0;
-            for (int s : nodes) {
-              const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
-              if (c >= nc) continue;
-              const int b = S.node_bcol0[s] + c;
-              if (!mine(b)) continue;
-              const BlockCol& B = S.bcols[b];
-              const int c0 = cs;
-              if (c0 >= B.width) continue;
-              const int pn = std::min(pw, B.width - c0);
-              ChainUnit u{};
-              u.off = B.off;
-              u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
-              u.ld = B.width;
-              u.c0 = c0;
-              u.pn = pn;
-              u.cs = cs;
-              u.ce = c0 + pn;
-              u.gcol = S.sptr[s] + B.r0 + c0;
-              P.chain_units.push_back(u);
-              fl += (double)pn * pn * pn / 3.0;
-            }
-            L.count = (int64_t)P.chain_units.size() - L.first;
-            L.flops = fl;
-            L.stream = ST_CHAIN;
-            if (la && g == 0) {
-              L.add_wait(zev(c));    // every inter-node update into block column c
-              L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
-            }
-            if (L.count > 0 || L.wait[0] >= 0) P.launches.push_back(L);
-          }
-          if (fuse_c || lite_c) {
+          if (fuse_c) {
             // the whole panel step in one launch (k_panel): POTRF, the rows below, and the
             // left-looking update of the next panel's columns
             Launch L;
@@ -834,7 +675,7 @@ struct Builder {
               u.gcol = S.sptr[s] + B.r0 + c0;
               const int nt = std::max(1, cdiv(below, 64));
               u.ntile = nt;
-              u.pad_ = lite_c ? 1 : 0;          // flag bit 0: the panel is already factored (chain launch above)
+              u.pad_ = 0;
               const int ui = (int)P.panel_units.size();
               P.panel_units.push_back(u);
               for (int t = 0; t < nt; ++t) P.tiles.push_back(UpdTile{ui, (short)t, 0});
@@ -843,12 +684,12 @@ struct Builder {
               P.flops_potrf += fp;
               P.flops_trsm += ft;
               P.flops_update += fu;
-              fl += (lite_c ? 0.0 : fp) + ft + fu;
+              fl += fp + ft + fu;
             }
             L.count = (int64_t)P.tiles.size() - L.first;
             L.flops = fl;
             L.stream = ST_CHAIN;
-            if (la && g == 0 && !lite_c) {
+            if (la && g == 0) {
               L.add_wait(zev(c));    // every inter-node update into block column c
               L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
             }
@@ -857,12 +698,12 @@ struct Builder {
             // follows on the other streams is ordered behind the updates into block column c
             // through them)
             if (L.count > 0 || L.record >= 0 || L.wait[0] >= 0) P.launches.push_back(L);
-          }
-          for (int q = 0; !fuse_c && !lite_c && q < maxq; ++q) {
-            // (1) chain step: panel q of the sub-tile, one workgroup per node
+          } else {
+            // (1) chain step: the diagonal block of the chunk, one workgroup per node -- one panel
+            // (k_chain_potrf) or a chain block of up to four (k_chain_block)
             {
               Launch L;
-              L.kind = chain2 ? L_CHAIN2 : L_CHAIN;
+              L.kind = blk4 ? L_CHAIN4 : L_CHAIN;
               L.level = lev;
               L.first = (int64_t)P.chain_units.size();
               L.tile = 0;
@@ -873,10 +714,10 @@ struct Builder {
                 const int b = S.node_bcol0[s] + c;
                 if (!mine(b)) continue;
                 const BlockCol& B = S.bcols[b];
-                const int c0 = cs + q * pq;
-                if (c0 >= std::min(B.width, cs + cb)) continue;
-                const int ce = std::min(B.width, cs + cb);
-                const int pn = std::min(pq, ce - c0);
+                const int c0 = cs;
+                if (c0 >= B.width) continue;
+                const int ce = std::min(B.width, cs + cstep);
+                const int pn = ce - c0;
                 ChainUnit u{};
                 u.off = B.off;
                 u.winv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
@@ -887,10 +728,15 @@ struct Builder {
                 u.ce = ce;
                 u.gcol = S.sptr[s] + B.r0 + c0;
                 P.chain_units.push_back(u);
-                const int below = ce - c0 - pn;
-                L.tile = std::max(L.tile, below);
-                const double fp = (double)pn * pn * pn / 3.0, ft = (double)below * pn * pn;
-                const double fu = (double)pn * ((double)below * (below + 1));
+                // the factorization of the pn x pn diagonal block, split as the one-panel steps
+                // would count it: Cholesky of the panels, solve and update of the blocks between
+                double fp = 0, ft = 0, fu = 0;
+                for (int q0 = 0; q0 < pn; q0 += pw) {
+                  const int qn = std::min(pw, pn - q0), below = pn - q0 - qn;
+                  fp += (double)qn * qn * qn / 3.0;
+                  ft += (double)below * qn * qn;
+                  fu += (double)qn * ((double)below * (below + 1));
+                }
                 P.flops_potrf += fp;
                 P.flops_trsm += ft;
                 P.flops_update += fu;
@@ -899,15 +745,13 @@ struct Builder {
               L.count = (int64_t)P.chain_units.size() - L.first;
               L.flops = fl;
               L.stream = ST_CHAIN;
-              if (la) {
-                if (g == 0 && q == 0) {
-                  L.add_wait(zev(c));    // every inter-node update into block column c
-                  L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
-                }
+              if (la && g == 0) {
+                L.add_wait(zev(c));    // every inter-node update into block column c
+                L.add_wait(evB_c2);    // bulk update (c-2 -> c..) wrote this tile
               }
               if (L.count > 0 || L.wait[0] >= 0) P.launches.push_back(L);   // (no unit of ours: the waits stay)
             }
-            // (2) rows below the panel: X = A(:, c0:c0+pn) inv(L_pp)^T
+            // (2) rows below the chunk: X = A(:, chunk) L_dd^-T
             double fl = 0;
             for (int s : nodes) {
               const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
@@ -915,10 +759,10 @@ struct Builder {
               const int b = S.node_bcol0[s] + c;
               if (!mine(b)) continue;
               const BlockCol& B = S.bcols[b];
-              const int c0 = cs + q * pq;
-              if (c0 >= std::min(B.width, cs + cb)) continue;
-              const int ce = std::min(B.width, cs + cb);
-              const int pn = std::min(pq, ce - c0);
+              const int c0 = cs;
+              if (c0 >= B.width) continue;
+              const int ce = std::min(B.width, cs + cstep);
+              const int pn = ce - c0;
               const int rows = B.nrow - ce;
               if (rows <= 0) continue;
               UpdUnit u{};
@@ -938,25 +782,29 @@ struct Builder {
               u.M = rows;
               u.N = pn;
               u.k0 = cs;
-              u.klen = c0 - cs + pn;
+              u.klen = pn;
               u.dinv_off = dinv_slot[b] + winv_offset(B.width, pw, cb, c0 / pw);
               u.dinv_ld = winv_ld(B.width, cb, c0);
               us.push_back(u);
-              const double ft = (double)rows * pn * pn, fu = 2.0 * rows * pn * (c0 - cs);
+              // (the count of the one-panel steps: triangular solves of the panels + the left-looking
+              // products between them)
+              double ft = 0, fu = 0;
+              for (int q0 = 0; q0 < pn; q0 += pw) {
+                const int qn = std::min(pw, pn - q0);
+                ft += (double)rows * qn * qn;
+                fu += 2.0 * rows * qn * q0;
+              }
               P.flops_trsm += ft;
               P.flops_update += fu;
               fl += ft + fu;
             }
-            static const int64_t trsm2_max = env_int("SPLLT_TRSM2_MAX", 2048);
-            int64_t nt64 = 0;
-            for (const UpdUnit& u : us) nt64 += cdiv(u.M, 64);
-            if (chain2 && !us.empty() && nt64 <= trsm2_max) {
-              // one workgroup per 64 rows and all columns of the chain block (k_trsm2)
+            if (blk4) {
+              // one workgroup per 32 rows and all columns of the chain block (k_trsm_rows)
               Launch L;
-              L.kind = L_TRSM2;
+              L.kind = L_TRSM4;
               L.level = lev;
               L.first = (int64_t)P.tiles.size();
-              L.tile = 64;
+              L.tile = 32;
               L.flops = fl;
               L.stream = ST_CHAIN;
               L.record = evD;
@@ -966,10 +814,10 @@ struct Builder {
                 u.a_w = S.bcols[u.src_bcol0].width;
                 u.a_off = S.bcols[u.src_bcol0].off;
                 P.units.push_back(u);
-                for (int ti = 0; ti < cdiv(u.M, 64); ++ti) P.tiles.push_back(UpdTile{uid, (short)ti, 0});
+                for (int ti = 0; ti < cdiv(u.M, 32); ++ti) P.tiles.push_back(UpdTile{uid, (short)ti, 0});
               }
               L.count = (int64_t)P.tiles.size() - L.first;
-              P.launches.push_back(L);
+              if (L.count > 0 || L.record >= 0) P.launches.push_back(L);   // (an empty launch still forwards the event)
               us.clear();
             } else {
               Edge e = edge(ST_CHAIN);
@@ -992,7 +840,7 @@ struct Builder {
                 if (c >= nc) continue;
                 const int b = S.node_bcol0[s] + c;
                 const BlockCol& B = S.bcols[b];
-                if (opt.top_owner[b] != r || cs >= B.width || cs + cb < B.width) continue;
+                if (opt.top_owner[b] != r || cs >= B.width || cs + cstep < B.width) continue;
                 const int64_t cnt = (int64_t)B.nrow * B.width;
                 P.xitems.push_back(ExchangeItem{b, r, o, cnt, B.off, 0});
                 o += cnt;
@@ -1026,28 +874,19 @@ struct Builder {
           // chunk's columns by everything left of them (chain stream: small launches that fit
           // the reserved CUs).  After the last chunk the whole block column updates block
           // column c+1 (chain stream) and c+2.. (bulk stream, beside the chain of c+1).
-          std::vector<UpdUnit> us_n1, us_n2, us_bulk, us_side;
-          double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0, fl_side = 0;
+          std::vector<UpdUnit> us_n1, us_n2, us_bulk;
+          double fl_n1 = 0, fl_n2 = 0, fl_bulk = 0;
           bool to_next_bcol = false;
-          // (the next step must be one of separate launches: a fused panel launch of c+1 would
-          // have to wait for the side launch as a whole)
-          bool split_here = false;
-          if (split_next && c + 1 < maxnc && opt.fused_panel && pw <= 64) {
-            const int64_t nt1 = row_blocks_of_step(c + 1);
-            split_here = nt1 > fused_max && nt1 > lite_max;
-          } else if (split_next && c + 1 < maxnc) {
-            split_here = true;
-          }
           for (int s : nodes) {
             const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
             if (c >= nc) continue;
             const int b = S.node_bcol0[s] + c;
             const BlockCol& B = S.bcols[b];
             if (cs >= B.width) continue;
-            const int ce = std::min(B.width, cs + cb);
+            const int ce = std::min(B.width, cs + cstep);
             if (ce < B.width) {
-              if (fuse_c || lite_c || !mine(b)) continue;   // part of the panel launch / the owner's business
-              const int ce2 = std::min(B.width, ce + cb);
+              if (fuse_c || !mine(b)) continue;   // part of the panel launch / the owner's business
+              const int ce2 = std::min(B.width, ce + cstep);
               // Left-looking inside the block column: the next panel's columns by everything left of
               // them.  Block columns wider than a SUPER-PANEL (256 columns) do that only inside the
               // current super-panel; when one is finished it updates ALL remaining columns of the
@@ -1071,18 +910,9 @@ struct Builder {
                 const BlockCol& D = S.bcols[bd];
                 if (jj == c + 1) {
                   to_next_bcol = true;
-                  if (split_here && D.width > pw && D.nrow > pw) {
-                    UpdUnit n1a = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, pw);
-                    UpdUnit n1b = direct_unit(b, 0, B.width, bd, pw, D.nrow - pw, pw, D.width - pw);
-                    us_n1.push_back(n1a);
-                    fl_n1 += direct_flops(n1a);
-                    us_side.push_back(n1b);
-                    fl_side += direct_flops(n1b);
-                  } else {
-                    UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
-                    us_n1.push_back(n1);
-                    fl_n1 += direct_flops(n1);
-                  }
+                  UpdUnit n1 = direct_unit(b, 0, B.width, bd, 0, D.nrow, 0, D.width);
+                  us_n1.push_back(n1);
+                  fl_n1 += direct_flops(n1);
                 } else {
                   // Trailing updates two source block columns at a time (K = 2 nb: the destination
                   // is read and written once for both, and the update kernel runs 10-15 % faster
@@ -1112,7 +942,7 @@ struct Builder {
               }
             }
           }
-          P.flops_update += fl_n1 + fl_n2 + fl_bulk + fl_side;
+          P.flops_update += fl_n1 + fl_n2 + fl_bulk;
           if (!us_n1.empty()) {
             Edge e = edge(ST_CHAIN);
             e.lat = 1;
@@ -1121,19 +951,8 @@ struct Builder {
                 e.wait1 = evB_c1;      // bulk (c-1 -> c+1..) writes the same entries
                 e.wait2 = zev(c + 1);  // and so do the inter-node updates into block column c+1
               }
-              if (g == 0) e.wait0 = ev_next_rest_in;   // the side launch of step c-1 wrote these columns
             }
             emit_gemm(lev, us_n1, fl_n1, true, e);
-          }
-          if (!us_side.empty()) {
-            Edge e = edge(ST_SIDE);
-            e.lat = 1;
-            e.wait0 = evD;             // block column c is final (the last solve of its rows)
-            e.wait1 = evB_c1;
-            e.wait2 = zev(c + 1);
-            ev_next_rest = P.nevents++;
-            e.record = ev_next_rest;
-            emit_gemm(lev, us_side, fl_side, true, e);
           }
           if (!us_n2.empty()) emit_gemm(lev, us_n2, fl_n2, true, edge(ST_CHAIN));   // single-stream program only
           if (g + 1 == ng) {

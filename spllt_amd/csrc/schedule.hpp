@@ -134,16 +134,15 @@ struct GatherTile {
 static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
 
 enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, /* 5: removed */ L_GATHER = 6,
-                        L_PANEL = 7, L_CHAIN2 = 8, L_TRSM2 = 9 };
-// L_TRSM2 (k_trsm2): the rows below a chain block solved by its inverse, X = A[:, block] W^T, one
-// workgroup per 64 rows and ALL the block's columns (tiles: unit, ti; TRSM-mode UpdUnits with
-// N = K = the block's width): the whole K extent of a row block is requested at once instead of
-// in 16-column steps (a tile of the throughput kernel needs 26 us for K = 128: eight dependent
-// round trips to memory).
-// L_CHAIN2 (k_chain_potrf2): one workgroup factors a whole CHAIN BLOCK of two panels (ChainUnit with
-// pn = its width, up to 2 kPanelMax) and emits its full inverse, so that the rows below are solved
-// for both panels by ONE product and updated by one launch: three launches per 128 columns of the
-// panel chain instead of six.
+                        L_PANEL = 7, L_CHAIN4 = 8, L_TRSM4 = 9 };
+// L_CHAIN4 (k_chain_block): one workgroup factors the whole diagonal block of a CHAIN BLOCK of up to
+// four panels (ChainUnit with pn = its width <= 4 pw) and emits the panels' inverses (per panel, the
+// layout of the one-panel chain steps).
+// L_TRSM4 (k_trsm_rows): the rows below a chain block solved against it, one workgroup per 32 rows and
+// ALL the block's columns (tiles: unit, ti; TRSM-mode UpdUnits with N = K = the block's width).  The
+// two replace, per chain block, up to four POTRF, four TRSM and three in-panel update launches of the
+// chain stream.  (Round 3's two-panel chain blocks -- k_chain_potrf2, which emitted a 128 x 128
+// inverse, and k_trsm2 -- measured equal to the one-panel steps and are gone.)
 
 // streams of the program: the chain (panel chain kernels and the updates that gate them),
 // (the side stream id is reserved: a variant that ran the rows below the sub-tiles one step
@@ -232,13 +231,9 @@ struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
   int cb = 64;          // ignored (chain block of the removed sub-tile chain kernels)
-  bool chain2 = false;  // chain blocks of TWO panels (L_CHAIN2 + L_TRSM2: three dependent launches per 128
-                        // columns of the panel chain instead of six); false: one panel per chain step.
-                        // Parity-clean and measured equal (23.66 vs 23.77 ms on the bench workload, 320.3
-                        // vs 318.7 on serena_like): what the saved launches gain, the 64^3 products of one
-                        // workgroup on ONE CU (1.7 us each: an fp64 MFMA holds a SIMD's matrix pipe for 64
-                        // cycles) take back -- k_chain_potrf2 34 us against 2 x 13.8, k_trsm2 14 us against
-                        // 2 x 8.  Off by default (SPLLT_CHAIN2=1).
+  bool chain4 = true;   // block-column steps whose block columns are wider than one panel: chain blocks of
+                        // up to FOUR panels (L_CHAIN4 + L_TRSM4, two dependent launches per 4 pw columns of the
+                        // panel chain instead of twelve); false (SPLLT_CHAIN4=0): one panel per chain step
   // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree
   // node, -1 for the (replicated) top tree.  With nranks > 1 the program is
   // [own subtrees] EXCHANGE [top tree].
@@ -268,22 +263,6 @@ struct ScheduleOptions {
   int super_panel = 256;      // block columns wider than this: left-looking panel updates only inside a
                               // super-panel of this many columns, one right-looking update of the rest of
                               // the block column per finished super-panel (0: left-looking throughout)
-  int lite_panel_max = 0;     // steps with more workgroups than fused_panel_max but at most this many: POTRF
-                              // launch + ONE k_panel launch for the rows (solve + left-looking update; the
-                              // workgroups read the inverted panel instead of factoring it).  0: off
-  bool split_next = false;    // the update of block column c+1 by c: only its first panel's columns on the
-                              // chain stream, the rest on the side stream beside the POTRF / solve of that
-                              // panel (SPLLT_SPLIT_NEXT=1).  Parity-clean (CPU DAG check + emulator, GPU residual)
-                              // and measured: 23.75-23.9 ms against 23.2-23.4 -- the side launch (three quarters
-                              // of the update) outlasts the POTRF + solve it runs beside, and the two event
-                              // hand-overs between the streams cost more than the overlap gives.  Off.
-  bool split_tail = false;    // the partly filled last round of a throughput launch is split along K into
-                              // several adding workgroups per tile (SPLLT_SPLIT_TAIL=1).  Parity-clean and
-                              // measured: single launches alone gain 2-4 % where the tail was long and lose up
-                              // to 10 % where the launch is only 1-2 rounds (more atomics, more workgroups);
-                              // 23.07 vs 23.04 ms on the bench workload -- inside the program the other streams
-                              // fill the tails anyway.  Off.
-  int tail_cus = 224;         // ... CUs such a launch runs on (the chip less the reserved CUs)
   int tile128_min = 4096;     // launches of up to this many 64-tiles keep 64-tiles (the 128-tile pays when a
                               // launch fills the chip for several rounds; throughput-bound problems: 1024)
   bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time

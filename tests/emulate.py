@@ -92,18 +92,23 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                     keep = np.tril(np.ones((ce - c0 - pn,) * 2, dtype=bool))
                     arena[ti[keep]] -= (X @ X.T)[keep]
             continue
-        if kind == 8:  # a chain block of two panels per unit (k_chain_potrf2): factor + full inverse
+        if kind == 8:  # a chain block of up to four panels per unit (k_chain_block): factor + per-panel inverses
+            pw = f.program("panel_width")
             for q in f.program("chains")[first:first + count]:
                 ld, off = int(q["ld"]), int(q["off"])
                 c0, cw = int(q["c0"]), int(q["pn"])
-                assert int(q["cs"]) == c0 and int(q["ce"]) == c0 + cw and cw <= 128
+                assert int(q["cs"]) == c0 and int(q["ce"]) == c0 + cw and cw <= 4 * pw and c0 % pw == 0
                 dd = off + np.arange(c0, c0 + cw)[:, None] * ld + np.arange(c0, c0 + cw)[None, :]
                 blk = np.tril(arena[dd])
                 Lb = sl.cholesky(blk + np.tril(blk, -1).T, lower=True)
                 low = np.tril_indices(cw)
                 arena[dd[low]] = Lb[low]
                 wo = int(q["winv_off"])
-                dinv[wo:wo + cw * cw] = sl.solve_triangular(Lb, np.eye(cw), lower=True).ravel()
+                for p0 in range(0, cw, pw):
+                    n = min(pw, cw - p0)
+                    inv = sl.solve_triangular(Lb[p0:p0 + n, p0:p0 + n], np.eye(n), lower=True)
+                    dinv[wo:wo + n * n] = inv.ravel()
+                    wo += n * n
             continue
         if kind == 7:  # one whole panel step per launch (k_panel), workgroup by workgroup
             pu = f.program("panels")
@@ -185,9 +190,15 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             u = units[int(t["unit"])]
             i0, j0 = int(t["ti"]) * T, int(t["tj"]) * T
             mi, nj = min(T, int(u["M"]) - i0), min(T, int(u["N"]) - j0)
-            if kind == 9:          # k_trsm2: 64 rows x ALL columns of the chain block per workgroup
-                assert u["mode"] == MODE_TRSM and j0 == 0 and T == 64
-                nj = int(u["N"])
+            if kind == 9:          # k_trsm_rows: 32 rows x ALL columns of the chain block per workgroup,
+                assert u["mode"] == MODE_TRSM and j0 == 0 and T == 32      # solved against its factored diagonal block
+                cw, ld, off = int(u["N"]), int(u["d_ld"]), int(u["d_off"])
+                cs, rr = int(u["d_col0"]), int(u["d_row0"]) + i0
+                assert int(u["k0"]) == cs and int(u["klen"]) == cw and int(u["d_row0"]) == cs + cw
+                dd = off + np.arange(cs, cs + cw)[:, None] * ld + np.arange(cs, cs + cw)[None, :]
+                xi = off + np.arange(rr, rr + mi)[:, None] * ld + np.arange(cs, cs + cw)[None, :]
+                arena[xi] = sl.solve_triangular(np.tril(arena[dd]), arena[xi].T, lower=True).T
+                continue
             assert mi > 0 and nj > 0
             P = np.zeros((mi, nj))
             for sg in range(int(u["nseg"])):

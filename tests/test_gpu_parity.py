@@ -607,21 +607,26 @@ def test_golden_vectors_gpu():
         np.testing.assert_allclose(f.solve(g["b"]), g["x"], rtol=0, atol=1e-11)
 
 
+@pytest.mark.parametrize("chain4", [1, 0])
 @pytest.mark.parametrize("flags", [0, 2, 512, 4096])
-@pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((12, 11, 10), 2), 160, 32),
-                                       (lambda: matgen.nd_like((14, 13, 12), 3), 256, None),
-                                       (lambda: matgen.fe27((9, 8, 8), 3), 200, 48)])
-def test_two_panel_chain_blocks_match_oracle(flags, gen, nb, pw, monkeypatch):
-    """SPLLT_CHAIN2=1: chain blocks of two panels -- k_chain_potrf2 factors a 128-wide diagonal
-    block and emits its whole inverse, k_trsm2 solves the rows below for both panels at once, the
-    left-looking update runs once per chain block (three dependent launches per 128 columns of
-    the panel chain instead of six); the dinv scratch then holds one cw x cw matrix per chain
-    block, which the device solve reads too."""
-    monkeypatch.setenv("SPLLT_CHAIN2", "1")
+@pytest.mark.parametrize("gen,nb,pw", [(lambda: matgen.nd_like((12, 11, 10), 2), 160, 32),     # 5 panels: 4 + 1
+                                       (lambda: matgen.nd_like((14, 13, 12), 3), 256, None),    # 256 = 4 x 64
+                                       (lambda: matgen.nd_like((14, 13, 12), 3), 200, None),    # 200 = 3 x 64 + 8
+                                       (lambda: matgen.fe27((9, 8, 8), 3), 200, 48),            # 4 x 48 + 8
+                                       (lambda: matgen.fe27((10, 9, 9), 3), 384, None)])        # 256 + 128
+def test_chain_blocks_match_oracle(chain4, flags, gen, nb, pw, monkeypatch):
+    """Chain blocks of up to four panels (default; SPLLT_CHAIN4=0: one panel per chain step):
+    k_chain_block factors the whole diagonal block of a chain block in one workgroup and emits the
+    panels' inverses, k_trsm_rows solves the rows below against it -- two dependent launches per
+    4 pw columns of the panel chain instead of twelve.  Block columns of 2, 3, 4 and 5+ panels,
+    ragged last panels, wider than one chain block (the right-looking update of the rest of the
+    block column in between); the device solve reads the same per-panel inverses either way."""
+    monkeypatch.setenv("SPLLT_CHAIN4", str(chain4))
     A = gen()
     f, val = make_case(A, nb=nb, nemin=16, panel_width=pw, engine_flags=flags)
     kinds = f.program("launches")[:, 0]
-    assert (kinds == 8).any() and (kinds == 9).any() and not (kinds == 4).any() and not (kinds == 7).any()
+    assert ((kinds == 8).any() and (kinds == 9).any()) == bool(chain4)
+    assert max(f.sym("bcol_width")) > (pw or 64), "the case is meant to have block columns of several panels"
     got = f.factor(val).wait().get_factor()
     o, rc = oracle_factor(f, val)
     assert rc == 0

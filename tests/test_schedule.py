@@ -125,7 +125,7 @@ def _access_sets(f):
     launches = f.program("launches")
     units, tiles, chains = f.program("units"), f.program("tiles"), f.program("chains")
     off, bw, bnr = f.sym("bcol_off"), f.sym("bcol_width"), f.sym("bcol_nrow")
-    pw = int(chains["pn"].max()) if len(chains) else 64
+    pw = int(f.program("panel_width"))
 
     def bcol_of(o):
         return int(np.searchsorted(off, o, side="right") - 1)
@@ -142,7 +142,7 @@ def _access_sets(f):
                 W.append((b, c0, ce, c0, ce))
                 W.append(("wi", b, c0 // pw))      # inverse part of Winv
         elif kind == 8:
-            # a chain block of two panels: factor of its diagonal block + the block's whole inverse
+            # a chain block of up to four panels: factor of its diagonal block + the panels' inverses
             for q in chains[first:first + count]:
                 b = bcol_of(q["off"])
                 c0, cw = int(q["c0"]), int(q["pn"])
@@ -195,6 +195,13 @@ def _access_sets(f):
         elif kind in (1, 9):
             for uid in sorted(set(tiles[first:first + count]["unit"].tolist())):
                 u = units[uid]
+                if kind == 9:
+                    # k_trsm_rows also reads the factored diagonal block of its chain block, and every
+                    # 32-row block of the unit has its workgroup
+                    b9, cs9, cw9 = bcol_of(u["d_off"]), int(u["d_col0"]), int(u["N"])
+                    R.append((b9, cs9, cs9 + cw9, cs9, cs9 + cw9))
+                    tl9 = tiles[first:first + count]
+                    assert sorted(tl9["ti"][tl9["unit"] == uid].tolist()) == list(range(-(-int(u["M"]) // 32)))
                 db = bcol_of(u["d_off"]) if u["mode"] != 3 else -1
                 M, N = int(u["M"]), int(u["N"])
                 for sg in range(int(u["nseg"])):
@@ -280,93 +287,6 @@ def dag_violations(f):
     return bad, launches, before, rec_at, last_in_stream
 
 
-@pytest.mark.parametrize("gen,nb,pw,nemin", [(lambda: matgen.nd_like((9, 8, 8), 2), 32, 16, 8),
-                                              (lambda: matgen.nd_like((9, 8, 8), 2), 8, 8, 8),
-                                              (lambda: matgen.poisson3d(12), 128, 64, 32),
-                                              (lambda: matgen.nd_like((10, 9, 9), 2), 64, 64, 16)])
-@pytest.mark.parametrize("cus,flags", [(1, 0), (3, 0), (16, 512)])
-def test_launch_tails_split_along_k(gen, nb, pw, nemin, cus, flags, monkeypatch):
-    """The last, partly filled round of a throughput launch is dealt along K to several workgroups
-    per tile (schedule.cpp split_tail): with a chip of 1 / 3 / 16 CUs every test-sized launch has
-    such a tail.  The pieces are units of their own -- K segments or a column window of the
-    tile's unit, adding atomically -- and the program must still order every conflict and give
-    the oracle's numbers."""
-    A = gen()
-    monkeypatch.setenv("SPLLT_SPLIT_TAIL", "0")
-    f0, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
-    u0, t0 = f0.program("units"), f0.program("tiles")
-    monkeypatch.setenv("SPLLT_SPLIT_TAIL", "1")
-    monkeypatch.setenv("SPLLT_TAIL_CUS", str(cus))
-    monkeypatch.setenv("SPLLT_SPLIT_MINK", "8")      # (test-sized block columns: 8-128 columns)
-    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
-    units, tiles, launches = f.program("units"), f.program("tiles"), f.program("launches")
-    assert len(launches) == len(f0.program("launches"))
-    np.testing.assert_allclose(launches[:, 5].sum(), f0.program("launches")[:, 5].sum(), rtol=1e-12)   # same flops
-    # a piece adds: scatter mode, or a direct unit marked atomic; never a solve / buffered unit
-    bw = f.sym("bcol_width")
-    pieces = 0
-    for l in launches:
-        if l[0] != 1 or l[3] == 0:
-            continue
-        tl = tiles[int(l[2]):int(l[2] + l[3])]
-        seen = {}
-        for t in tl:
-            seen.setdefault((int(t["ti"]), int(t["tj"]), int(units[t["unit"]]["d_off"]), int(units[t["unit"]]["relrow_off"]),
-                             int(units[t["unit"]]["d_row0"]), int(units[t["unit"]]["d_col0"]), int(units[t["unit"]]["src_r0"])), []).append(int(t["unit"]))
-        for key, us in seen.items():
-            if len(us) < 2:
-                continue
-            pieces += len(us)
-            assert l[6] in (1, 2), "only launches of the bulk / far streams are split"
-            ks = []
-            for uid in us:
-                u = units[uid]
-                assert u["mode"] == 1 or (u["mode"] == 0 and u["atomic"] == 1)
-                for sg in range(int(u["nseg"])):
-                    b = int(u["src_bcol0"]) + sg
-                    k0 = int(u["k0"]) if (u["nseg"] == 1 and u["klen"] >= 0) else 0
-                    k1 = k0 + int(u["klen"]) if (u["nseg"] == 1 and u["klen"] >= 0) else int(bw[b])
-                    ks.append((b, k0, k1))
-            ks.sort()
-            for (b0, a0, a1), (b1, c0, c1) in zip(ks, ks[1:]):      # the K ranges of the pieces are disjoint
-                assert b1 > b0 or c0 >= a1, ks
-    assert (pieces > 0) == (len(units) > len(u0))
-    if nb == 8 or (nb, cus) in ((32, 1), (32, 3), (64, 1), (128, 3)):
-        assert pieces > 0, "this case is known to have tails that split"
-    bad, *_ = dag_violations(f)
-    assert not bad, bad[:3]
-    got = emulate_program(f, val)
-    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
-
-
-@pytest.mark.parametrize("case", ["nd-32-16", "nd-8-8", "p3d-24-8", "nd-100-8"])
-@pytest.mark.parametrize("flags", [0, 512, 2048, 2, 4096])
-def test_next_block_column_update_split_over_chain_and_side_stream(case, flags, monkeypatch):
-    """ScheduleOptions::split_next (SPLLT_SPLIT_NEXT=1): of the update of block column c+1 by c only
-    the first panel's columns stay on the chain stream; the rest runs on the side stream beside the
-    POTRF / solve of that panel, and the first in-panel update of c+1 waits for it.  The DAG must
-    still order every conflict, the numbers must be the oracle's, the flops the same."""
-    gen, nb, pw = _DAG_GENS[case]
-    A = gen()
-    monkeypatch.setenv("SPLLT_FUSED_PANEL_MAX", "2")     # (test-sized steps would all be fused panel launches)
-    f0, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
-    L0 = f0.program("launches")       # (the host-side program is built when it is asked for)
-    monkeypatch.setenv("SPLLT_SPLIT_NEXT", "1")
-    f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
-    L = f.program("launches")
-    side = L[:, 6] == 3
-    if flags & (2 | 4096):            # single-stream program, deterministic engine: nothing is split
-        assert not side.any()
-    elif case.startswith("nd-") and nb > pw:      # (nodes of several block columns wider than a panel, steps of separate launches)
-        assert side.any() and not (L0[:, 6] == 3).any()
-        assert (L[side, 7] >= 0).all(), "every side launch records the event its columns' first reader waits for"
-    np.testing.assert_allclose(L[:, 5].sum(), L0[:, 5].sum(), rtol=1e-12)
-    bad, *_ = dag_violations(f)
-    assert not bad, bad[:3]
-    got = emulate_program(f, val)
-    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
-
-
 _DAG_GENS = {"nd-32-16": (lambda: matgen.nd_like((9, 8, 8), 2), 32, 16),
              "p2d-16-16": (lambda: matgen.poisson2d(40), 16, 16),
              "p3d-24-8": (lambda: matgen.poisson3d(9), 24, 8),
@@ -388,32 +308,35 @@ def _dag_cases():
     return out
 
 
-@pytest.mark.parametrize("case,cb,flags,chain2", _dag_cases())
-def test_stream_dag_orders_every_conflict(case, cb, flags, chain2, monkeypatch):
+@pytest.mark.parametrize("case,cb,flags,chain4", _dag_cases())
+def test_stream_dag_orders_every_conflict(case, cb, flags, chain4, monkeypatch):
     gen, nb, pw = _DAG_GENS[case]
-    _stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain2, monkeypatch)
+    _stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain4, monkeypatch)
 
 
-def _stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain2, monkeypatch):
+def _stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain4, monkeypatch):
     """Multi-stream program (chain, side, bulk, far, wide): any two launches that touch the
     same entries (write/write, read/write, atomic/plain) must be ordered by stream order or
     an event edge; concurrent atomics into one destination are fine.  cb: the (ignored) chain
-    block knob; chain2: chain blocks of two panels (k_chain_potrf2 + k_trsm2) or one panel per
-    chain step (with the fused k_panel launches; the default)."""
+    block knob; chain4: chain blocks of up to four panels (k_chain_block + k_trsm_rows; the default)
+    for steps with block columns of several panels, or one panel per chain step throughout."""
     if cb:
         monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
-    monkeypatch.setenv("SPLLT_CHAIN2", str(chain2))
+    monkeypatch.setenv("SPLLT_CHAIN4", str(chain4))
     A = gen()
     f, val = make_case(A, nb=nb, nemin=8, panel_width=pw, engine_flags=flags)
     bad, launches, before, rec_at, last_in_stream = dag_violations(f)
     assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
     assert not (launches[:, 6] == 3).any(), "the side stream is not used"
-    if chain2:
-        assert (launches[:, 0] == 8).any() and not (launches[:, 0] == 4).any() and not (launches[:, 0] == 7).any()
+    kinds = launches[:, 0]
+    if chain4 and nb > pw:       # block columns of several panels: chain blocks + their row solves
+        assert (kinds == 8).any() and (kinds == 9).any()
     else:
+        assert not (kinds == 8).any() and not (kinds == 9).any()
+    if not chain4:
         fused = not flags & 512      # fused panel launches replace the chain steps (the chain block knob is ignored)
-        assert (launches[:, 0] == (7 if fused else 4)).any() and not (launches[:, 0] == (4 if fused else 7)).any()
+        assert (kinds == (7 if fused else 4)).any() and not (kinds == (4 if fused else 7)).any()
     assert ((launches[:, 0] == 6).any()) == bool(flags & 4096), "gather launches only in the deterministic engine"
     if flags & 4096:
         units = f.program("units")
@@ -437,23 +360,23 @@ def test_single_stream_program_has_no_events():
 
 @pytest.mark.parametrize("flags", [0, 2, 64, 66, 512, 514, 1024, 2048, 4096, 4098, 4608])
 @pytest.mark.parametrize("cb", [0, 16, 32])
-@pytest.mark.parametrize("chain2", [1, 0])
-def test_program_variants_agree(flags, cb, chain2, monkeypatch):
+@pytest.mark.parametrize("chain4", [1, 0])
+def test_program_variants_agree(flags, cb, chain4, monkeypatch):
     """multi-stream / single-stream programs, with and without early inter-node slices, zone
-    pipeline forced on / off, deterministic engine, chain blocks of two panels or one panel per
-    chain step: all reproduce the same factor (interpreted in numpy)."""
+    pipeline forced on / off, deterministic engine, chain blocks of up to four panels or one panel
+    per chain step: all reproduce the same factor (interpreted in numpy)."""
     if cb:
         monkeypatch.setenv("SPLLT_CHAIN_BLOCK", str(cb))
-    monkeypatch.setenv("SPLLT_CHAIN2", str(chain2))
+    monkeypatch.setenv("SPLLT_CHAIN4", str(chain4))
     A = matgen.nd_like((8, 7, 7), 2)
     f, val = make_case(A, nb=48, nemin=8, panel_width=16, engine_flags=flags)
-    assert f.program("chain_block") == (32 if chain2 else 16)   # two panels / one, whatever the knob asks for
+    assert f.program("chain_block") == 16 and f.program("panel_width") == 16   # the inverses stay per panel
     kinds = f.program("launches")[:, 0]
     assert not (kinds == 5).any()
-    if chain2:
-        assert (kinds == 8).any() and not (kinds == 7).any() and not (kinds == 4).any()
+    if chain4:
+        assert (kinds == 8).any() and (kinds == 9).any()      # (48-wide block columns: three panels)
     else:
-        assert (kinds == 7).any() == (not flags & 512), "fused panel launches unless flag 512"
+        assert not (kinds == 8).any() and (kinds == 7).any() == (not flags & 512), "fused panel launches unless flag 512"
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
 
