@@ -202,6 +202,13 @@ __device__ unsigned long long g_potrf_stamps[32];
 #define STAMP2(c, i) do { } while (0)
 #endif
 
+#ifdef CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[64];
+#define CSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+
 struct PotrfShared {
   double X[64 * TLD];
   double DI[4][16 * DLD];
@@ -865,6 +872,29 @@ __device__ __forceinline__ void mma_64(const double* __restrict__ a, const doubl
   }
 }
 
+// the same product with the operand fragments requested in two halves (48 instead of 96 registers
+// in flight: for kernels that hold other blocks in registers meanwhile)
+__device__ __forceinline__ void mma_64_lean(const double* __restrict__ a, const double* __restrict__ b, int s,
+                                            int jb0, int lane, d4& acc0, d4& acc1) {
+  const int lq = lane >> 4, lr = lane & 15;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    double av[8], b0[8], b1[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      av[kt] = a[(s * 16 + lr) * TLD + 4 * (8 * hf + kt) + lq];
+      b0[kt] = b[(jb0 * 16 + lr) * TLD + 4 * (8 * hf + kt) + lq];
+      b1[kt] = b[((jb0 + 1) * 16 + lr) * TLD + 4 * (8 * hf + kt) + lq];
+    }
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b0[kt], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kt], b1[kt], acc1, 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 __device__ __forceinline__ void mma_64x4(const double* __restrict__ a, const double* __restrict__ b, int s,
                                          int lane, d4 (&acc)[4]) {
 #pragma unroll
@@ -1075,25 +1105,48 @@ __global__ __launch_bounds__(kPanelThreads) void k_chain_block(const ChainUnit* 
   const int np = (cw + pw - 1) / pw;
   double* A = L + u.off + (int64_t)u.c0 * ld + u.c0;   // entry (0, 0) of the diagonal block
   double* W = dinv + u.winv_off;                        // slot of the block's first panel; panel p: + p pw^2
+  // (offsets, not pointers: a select between LDS pointers goes through generic pointers, and this
+  // compiler then emits a compare against src_shared_base that its own verifier rejects)
+  constexpr int kPaOff = (int)(sizeof(PotrfShared) / sizeof(double));
+  constexpr int kTOff = (int)(offsetof(PotrfShared, T) / sizeof(double));
+  auto pbuf = [&](int q) { return cblk_smem + (q == 0 ? kPaOff : (q == 1 ? kPaOff + 64 * TLD : kTOff)); };
+  CSTAMP(0);
   for (int p = 0; p < np; ++p) {
     const int n_p = min(pw, cw - p * pw);
-    potrf64(sh, A + (int64_t)(p * pw) * ld + p * pw, ld, n_p, W + (int64_t)p * pw * pw, n_p, u.gcol + p * pw, 8,
-            flag);
+    // (from the second panel on, the diagonal block is already in sh.T: the update phase below
+    // put it there instead of sending it through the arena)
+    potrf64(sh, A + (int64_t)(p * pw) * ld + p * pw, ld, n_p, W + (int64_t)p * pw * pw, n_p, u.gcol + p * pw,
+            p == 0 ? 8 : (8 | 16), flag);
     __syncthreads();                                    // (the tail of potrf64 still read sh.T / sh.X)
+    CSTAMP(1 + 5 * p);
     const int nbel = np - 1 - p;                        // blocks below this panel (<= 3)
     if (nbel == 0) break;
-    // (offsets, not pointers: a select between LDS pointers goes through generic pointers, and this
-    // compiler then emits a compare against src_shared_base that its own verifier rejects)
-    constexpr int kPaOff = (int)(sizeof(PotrfShared) / sizeof(double));
-    constexpr int kTOff = (int)(offsetof(PotrfShared, T) / sizeof(double));
-    auto pbuf = [&](int q) { return cblk_smem + (q == 0 ? kPaOff : (q == 1 ? kPaOff + 64 * TLD : kTOff)); };
-    // ---- L_ip = A_ip W_pp^T, into LDS (operands of the updates) and home ------------------
+    if (p == 0) {
 #pragma unroll 1
-    for (int q = 0; q < nbel; ++q) {
-      const int i = p + 1 + q, n_i = min(pw, cw - i * pw);
-      stage_block(pbuf(q), A + (int64_t)(i * pw) * ld + p * pw, ld, n_i, n_p, tid);
+      for (int q = 0; q < nbel; ++q) {
+        const int i = 1 + q, n_i = min(pw, cw - i * pw);
+        stage_block(pbuf(q), A + (int64_t)(i * pw) * ld, ld, n_i, n_p, tid);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    // the destination entries of a trailing block in accumulator layout (clamped, unconditional)
+    auto cload = [&](int a, int b, d4& v0, d4& v1) {
+      const int i = p + 1 + a, j = p + 1 + b;
+      const int n_i = min(pw, cw - i * pw), n_j = min(pw, cw - j * pw);
+      const double* C = A + (int64_t)(i * pw) * ld + j * pw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s * 16 + lq + 4 * r;
+        const double* crow = C + (int64_t)(row < n_i ? row : n_i - 1) * ld;
+        const int ca = jb0 * 16 + lr, cb2 = ca + 16;
+        v0[r] = crow[ca < n_j ? ca : n_j - 1];
+        v1[r] = crow[cb2 < n_j ? cb2 : n_j - 1];
+      }
+    };
+    CSTAMP(2 + 5 * p);
+    d4 c0v, c1v, n0v = {0.0, 0.0, 0.0, 0.0}, n1v = n0v;
+    cload(0, 0, c0v, c1v);                              // flies during the solves
+    // ---- L_ip = A_ip W_pp^T, into LDS (operands of the updates) and home ------------------
     // (runtime loops, one block at a time: unrolled, the operand fragments of all blocks are
     // requested at once and the kernel spills)
 #pragma unroll 1
@@ -1101,7 +1154,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_chain_block(const ChainUnit* 
       const int i = p + 1 + q, n_i = min(pw, cw - i * pw);
       double* Pq = pbuf(q);
       d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
-      mma_64(Pq, sh.X, s, jb0, lane, x0, x1);
+      mma_64_lean(Pq, sh.X, s, jb0, lane, x0, x1);
       __syncthreads();                                  // everybody has read the A_ip image
       double* dst = A + (int64_t)(i * pw) * ld + p * pw;
 #pragma unroll
@@ -1117,44 +1170,44 @@ __global__ __launch_bounds__(kPanelThreads) void k_chain_block(const ChainUnit* 
       }
     }
     __syncthreads();
+    CSTAMP(3 + 5 * p);
     // ---- A_ij -= L_ip L_jp^T, i >= j > p: the destination entries of the next block are
-    // requested before the product of the current one ---------------------------------------
-    {
-      d4 c0v = {0.0, 0.0, 0.0, 0.0}, c1v = {0.0, 0.0, 0.0, 0.0}, n0v = c0v, n1v = c0v;
-      auto cload = [&](int a, int b, d4& v0, d4& v1) {
-        const int i = p + 1 + a, j = p + 1 + b;
-        const int n_i = min(pw, cw - i * pw), n_j = min(pw, cw - j * pw);
-        const double* C = A + (int64_t)(i * pw) * ld + j * pw;
+    // requested before the product of the current one.  The blocks of the NEXT panel's column
+    // (b == 0) do not go back to the arena: the diagonal one becomes the input of the next
+    // factorization in sh.T, the ones below it the staged operands of the next solves.
+    d4 k0[3], k1[3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = s * 16 + lq + 4 * r;
-          const double* crow = C + (int64_t)(row < n_i ? row : n_i - 1) * ld;
-          const int ca = jb0 * 16 + lr, cb2 = ca + 16;
-          v0[r] = crow[ca < n_j ? ca : n_j - 1];
-          v1[r] = crow[cb2 < n_j ? cb2 : n_j - 1];
-        }
-      };
-      cload(0, 0, c0v, c1v);
-      // the blocks (a, b), b <= a < nbel, row by row
+    for (int a = 0; a < 3; ++a) k0[a] = k1[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    {
       int a = 0, b = 0;
       const int nupd = nbel * (nbel + 1) / 2;
 #pragma unroll 1
       for (int t = 0; t < nupd; ++t) {
+        // (the blocks row by row: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2))
         const int a2 = b < a ? a : a + 1, b2 = b < a ? b + 1 : 0;
         if (t + 1 < nupd) cload(a2, b2, n0v, n1v);
         const int i = p + 1 + a, j = p + 1 + b;
         const int n_i = min(pw, cw - i * pw), n_j = min(pw, cw - j * pw);
         d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
-        mma_64(pbuf(a), pbuf(b), s, jb0, lane, m0, m1);
-        double* C = A + (int64_t)(i * pw) * ld + j * pw;
+        mma_64_lean(pbuf(a), pbuf(b), s, jb0, lane, m0, m1);
+        if (b == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = s * 16 + lq + 4 * r;
-          const int ca = jb0 * 16 + lr, cb2 = ca + 16;
-          if (row >= n_i) continue;
-          // (diagonal blocks: the lower triangle only -- what lies above it is never written)
-          if (ca < n_j && (a != b || ca <= row)) C[(int64_t)row * ld + ca] = c0v[r] - m0[r];
-          if (cb2 < n_j && (a != b || cb2 <= row)) C[(int64_t)row * ld + cb2] = c1v[r] - m1[r];
+          for (int aa = 0; aa < 3; ++aa)
+            if (aa == a) {
+              k0[aa] = c0v - m0;
+              k1[aa] = c1v - m1;
+            }
+        } else {
+          double* C = A + (int64_t)(i * pw) * ld + j * pw;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = s * 16 + lq + 4 * r;
+            const int ca = jb0 * 16 + lr, cb2 = ca + 16;
+            if (row >= n_i) continue;
+            // (diagonal blocks: the lower triangle only -- what lies above it is never written)
+            if (ca < n_j && (a != b || ca <= row)) C[(int64_t)row * ld + ca] = c0v[r] - m0[r];
+            if (cb2 < n_j && (a != b || cb2 <= row)) C[(int64_t)row * ld + cb2] = c1v[r] - m1[r];
+          }
         }
         c0v = n0v;
         c1v = n1v;
@@ -1162,126 +1215,180 @@ __global__ __launch_bounds__(kPanelThreads) void k_chain_block(const ChainUnit* 
         b = b2;
       }
     }
-    // the next factorization reads A_{p+1,p+1} from the arena, the next solves the rest
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();                                    // everybody has read the L_ip images
+    CSTAMP(4 + 5 * p);
+    {
+      const int n_n = min(pw, cw - (p + 1) * pw);      // the next panel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s * 16 + lq + 4 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int col = (jb0 + h) * 16 + lr;
+          // identity-padded lower triangle, the image potrf64 builds for itself (flag 16)
+          sh.T[row * TLD + col] = (row < n_n && col <= row) ? (h ? k1[0][r] : k0[0][r]) : (row == col ? 1.0 : 0.0);
+#pragma unroll
+          for (int aa = 1; aa < 3; ++aa) {
+            if (aa >= nbel) continue;
+            const int n_i = min(pw, cw - (p + 1 + aa) * pw);
+            pbuf(aa - 1)[row * TLD + col] = (row < n_i && col < n_n) ? (h ? k1[aa][r] : k0[aa][r]) : 0.0;
+          }
+        }
+      }
+    }
+    // (potrf64 begins with a barrier of its own behind clearing sh.X)
+    CSTAMP(5 + 5 * p);
   }
 }
 
 // ---------------------------------------------------------------------------
 // The rows below a chain block, solved against its factored diagonal block (a12 spllt_solve_block,
-// kernels_mod:1217-1229, for all panels of the block at once): one workgroup per 32 rows and ALL
+// kernels_mod:1217-1229, for all panels of the block at once): one workgroup per 64 rows and ALL
 // cw <= 4 pw columns of the block (UpdTile: unit, ti; the unit a TRSM-mode UpdUnit with N = cw),
 //   X_p = (A_p - sum_{q<p} X_q L_pq^T) W_pp^T,   p = 0 .. np-1,
-// ten 32 x 64 x 64 products for a 256-wide block, every operand block (L_pq from the arena, W_pp
-// from the dinv scratch: both written by k_chain_block) requested one product ahead, the X_q kept
-// in LDS as operands.  In place: a workgroup reads its rows before it writes them and nobody
-// else touches them.  Replaces, per 256 columns, four TRSM launches (K = 64: 151 launches at 3
-// TFLOP/s on the bench workload) and three in-panel update launches on the chain stream.
+// computed TRANSPOSED, Y_p = X_p^T = W_pp (A_p^T - sum_q L_pq Y_q): the blocks of the diagonal
+// factor (L_pq, W_pp: written by k_chain_block) are the MFMA A operands, staged through LDS for
+// the whole workgroup, and a wave keeps the Y of its 16 rows in registers, where an accumulator
+// tile (register r of lane l: row (l >> 4) + 4 r, column l & 15) IS the B operand of k-step r of
+// the next product -- nothing of X goes through LDS.  Within every group of 16 columns the
+// accumulator row (l >> 4) + 4 r stands for column 4 (l >> 4) + r (perm4 below), so that a lane
+// holds four consecutive columns of a row (32-byte loads / stores); the staged operand blocks
+// are permuted the same way in both directions, which keeps the operand reads on the
+// conflict-free pattern of mma_64.  LDS: two operand stages (68 KB): two workgroups per CU.
+// In place: a workgroup reads its rows before it writes them and nobody else touches them.
+// Replaces, per 256 columns, four TRSM launches (K = 64: 151 launches at 3 TFLOP/s on the bench
+// workload) and three in-panel update launches on the chain stream.
 // ---------------------------------------------------------------------------
-constexpr int kTrsmRows = 32;
-__global__ __launch_bounds__(256) void k_trsm_rows(const UpdTile* __restrict__ tiles,
-                                                   const UpdUnit* __restrict__ units,
-                                                   double* __restrict__ L,
-                                                   const double* __restrict__ dinv, int pw, int prio) {
+constexpr int kTrsmRows = 64;
+__device__ __forceinline__ int perm4(int x) { return (x & ~15) | ((x & 3) << 2) | ((x >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void k_trsm_rows(const UpdTile* __restrict__ tiles,
+                                                      const UpdUnit* __restrict__ units,
+                                                      double* __restrict__ L,
+                                                      const double* __restrict__ dinv, int pw, int prio) {
   extern __shared__ __attribute__((aligned(16))) double trows_smem[];
-  double* XS = trows_smem;                          // X_0 .. X_2 as operands: [3][32][TLD]
-  double* G = XS + 3 * kTrsmRows * TLD;             // A_p - sum X_q L_pq^T as an operand
-  double* Bst = G + kTrsmRows * TLD;                // [2][64][TLD]: L_pq / W_pp
+  double* Bst = trows_smem;                         // [2][64][TLD]: L_pq / W_pp, permuted
   if (prio) __builtin_amdgcn_s_setprio(3);
+  CSTAMP(60);
   const UpdTile tl = tiles[blockIdx.x];
   const UpdUnit u = units[tl.unit];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-  const int s = wave >> 1, jb0 = (wave & 1) * 2;
   const int cw = u.N, ld = u.d_ld;
   const int np = (cw + pw - 1) / pw;
   const int r0 = (int)tl.ti * kTrsmRows, nr = min(kTrsmRows, u.M - r0);
   double* X = L + u.d_off + (int64_t)(u.d_row0 + r0) * ld + u.d_col0;
   const double* Ld = L + u.d_off + (int64_t)u.d_col0 * ld + u.d_col0;    // the factored diagonal block
   const double* W = dinv + u.dinv_off;
-  // this workgroup's rows, in accumulator layout, all panels at once
-  double av[4][2][4];
+  CSTAMP(61);
+  // this lane's row of the block and its four consecutive columns 16 i + 4 lq + (0..3) of panel pp
+  const int myrow = wave * 16 + lr;
+  const bool row_ok = myrow < nr;
+  double* Xrow = X + (int64_t)(row_ok ? myrow : nr - 1) * ld;
+  auto aload = [&](int pp, d4 (&v)[4]) {
+    const int n_pp = min(pw, cw - pp * pw);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int n_p = min(pw, cw - p * pw);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = s * 16 + lq + 4 * r, col = (jb0 + h) * 16 + lr;
-        double v = 0.0;
-        if (p < np) v = X[(int64_t)(row < nr ? row : nr - 1) * ld + p * pw + (col < n_p ? col : n_p - 1)];
-        av[p][h][r] = (p < np && row < nr && col < n_p) ? v : 0.0;
+        const int col = 16 * i + 4 * lq + r;
+        v[i][r] = Xrow[pp * pw + (col < n_pp ? col : n_pp - 1)];
       }
-  }
-  // operand blocks, one product ahead: 64 x 64 through 16 registers per thread
+  };
+  // Operand blocks (64 x 64, 16 registers per thread each) are requested kDepth products ahead.
+  // The blocks in the order they are used, (p, q): q < p is L_pq, q == p is W_pp.
+  constexpr int kDepth = 1;
+  constexpr int PT[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
+  constexpr int QT[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+  const int nT = np * (np + 1) / 2;
   const int fr = tid >> 3, fc = tid & 7;
-  double bv[16];
-  int cur_nrow = 0, cur_ncol = 0;
-  auto fetch = [&](int p, int q) {
-    const int n_p = min(pw, cw - p * pw);
-    const double* src;
-    int64_t l;
-    if (q == p) { src = W + (int64_t)p * pw * pw; l = n_p; cur_ncol = n_p; }
-    else { src = Ld + (int64_t)(p * pw) * ld + q * pw; l = ld; cur_ncol = pw; }
-    cur_nrow = n_p;
+  double bv[kDepth][16];
+  auto blk_rows = [&](int pp) { return min(pw, cw - pp * pw); };
+  auto blk_cols = [&](int pp, int qq) { return qq == pp ? min(pw, cw - pp * pw) : pw; };
+  auto fetch = [&](int pp, int qq, double (&v)[16]) {
+    const int nrow = blk_rows(pp), ncol = blk_cols(pp, qq);
+    const double* src = qq == pp ? W + (int64_t)pp * pw * pw : Ld + (int64_t)(pp * pw) * ld + qq * pw;
+    const int64_t l = qq == pp ? nrow : ld;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = fr + 32 * h;
-      const double* row = src + (int64_t)(r < cur_nrow ? r : cur_nrow - 1) * l;
+      const double* row = src + (int64_t)(r < nrow ? r : nrow - 1) * l;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[8 * h + e] = row[fc + 8 * e < cur_ncol ? fc + 8 * e : cur_ncol - 1];
+      for (int e = 0; e < 8; ++e) v[8 * h + e] = row[fc + 8 * e < ncol ? fc + 8 * e : ncol - 1];
     }
   };
-  fetch(0, 0);
-  int t = 0;
-  for (int p = 0; p < np; ++p) {
-    const int n_p = min(pw, cw - p * pw);
-    d4 m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
-    for (int q = 0; q <= p; ++q, ++t) {
-      double* B = Bst + (t & 1) * (64 * TLD);
+  d4 ac[4];                   // A_p^T of the next panel to start (accumulator layout), requested a step ahead
+  aload(0, ac);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = fr + 32 * h;
+  for (int t = 0; t < kDepth; ++t)
+    if (t < nT) fetch(PT[t], QT[t], bv[t]);
+  d4 Yn[3][4];                // -Y_0 .. -Y_2: this wave's 16 rows, all 64 columns of a panel each
+  d4 g[4];                    // A_p^T - sum_q L_pq Y_q
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          B[r * TLD + fc + 8 * e] = (r < cur_nrow && fc + 8 * e < cur_ncol) ? bv[8 * h + e] : 0.0;
+  for (int i = 0; i < 4; ++i) g[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  CSTAMP(32);
+  // acc[i] += sum_k Ablk[16 i + .][k] Bf[k / 16][.]   (Ablk: a permuted LDS image, Bf: four accumulator
+  // tiles); the operand fragments of k-step r + 1 are read while the MFMAs of step r issue
+  auto product = [&](const double* __restrict__ Ablk, const d4 (&Bf)[4], d4 (&acc)[4]) {
+    const double* ap = Ablk + lr * TLD + lq;
+    double a[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = ap[(16 * i) * TLD];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[(ks + 1) & 1][i] = ap[(16 * i) * TLD + 4 * (ks + 1)];
       }
-      if (q == p) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks & 1][i], Bf[ks >> 2][ks & 3], acc[i], 0, 0, 0);
+    }
+  };
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = s * 16 + lq + 4 * r, col = (jb0 + h) * 16 + lr;
-            double a = 0.0;
+  for (int t = 0; t < 10; ++t) {
+    if (t >= nT) continue;            // (uniform; a `break` would keep the loop from unrolling: ring slots in scratch)
+    const int p = PT[t], q = QT[t];
+    const int n_p = blk_rows(p), ncol = blk_cols(p, q);
+    double* B = Bst + (t & 1) * (64 * TLD);
+    // the operand block into LDS, rows and columns permuted within their groups of 16
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) a = pp == p ? av[pp][h][r] : a;
-            G[row * TLD + col] = a - (h ? m1[r] : m0[r]);
-          }
-      }
-      // the next operand block flies during this product
-      if (q < p) fetch(p, q + 1);
-      else if (p + 1 < np) fetch(p + 1, 0);
-      __syncthreads();
-      if (q < p) {
-        mma_64(XS + q * (kTrsmRows * TLD), B, s, jb0, lane, m0, m1);
-      } else {
-        d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
-        mma_64(G, B, s, jb0, lane, x0, x1);
-        double* Xp = XS + (p < 3 ? p : 0) * (kTrsmRows * TLD);
+    for (int h = 0; h < 2; ++h) {
+      const int r = fr + 32 * h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        B[perm4(r) * TLD + perm4(fc + 8 * e)] = (r < n_p && fc + 8 * e < ncol) ? bv[t % kDepth][8 * h + e] : 0.0;
+    }
+    if (t + kDepth < 10 && t + kDepth < nT)
+      fetch(PT[t + kDepth < 10 ? t + kDepth : 9], QT[t + kDepth < 10 ? t + kDepth : 9], bv[t % kDepth]);
+    if (q == 0) {
+      // G = A_p^T (masked: rows / columns beyond the block are exact zeros); the next panel's rows are requested
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[i][r] = (row_ok && 16 * i + 4 * lq + r < n_p) ? ac[i][r] : 0.0;
+      if (p + 1 < np) aload(p + 1 < 4 ? p + 1 : 3, ac);
+    }
+    __syncthreads();
+    CSTAMP(33 + 2 * t);
+    if (q < p) {
+      product(B, Yn[q < 3 ? q : 0], g);              // G += L_pq (-Y_q)
+    } else {
+      d4 y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = (d4){0.0, 0.0, 0.0, 0.0};
+      product(B, g, y);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = s * 16 + lq + 4 * r;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int col = (jb0 + h) * 16 + lr;
-            const double v = col < n_p ? (h ? x1[r] : x0[r]) : 0.0;     // padding columns: exact zeros
-            if (p + 1 < np) Xp[row * TLD + col] = v;
-            if (row < nr && col < n_p) X[(int64_t)row * ld + p * pw + col] = v;
-          }
+          const int col = 16 * i + 4 * lq + r;
+          if (col >= n_p) y[i][r] = 0.0;                 // padding columns: exact zeros
+          if (row_ok && col < n_p) X[(int64_t)myrow * ld + p * pw + col] = y[i][r];
         }
+        if (p < 3) Yn[p < 3 ? p : 0][i] = -y[i];
       }
     }
+    CSTAMP(34 + 2 * t);
   }
 }
 
@@ -1535,6 +1642,32 @@ __device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
       const int j = j0 + coff(b) + lc;
       dcol[b] = (b < nbf && j < N) ? rlist[u.gcol_off + j] - u.d_col0 : -1;
     }
+#if defined(SCATTER_EXPERIMENT) && SCATTER_EXPERIMENT == 5
+    // (timing only: plain read-modify-write with the loads of a fragment row batched -- what an
+    // epilogue that OWNS its destination entries would issue; races between units ignored)
+#pragma unroll
+    for (int a = 0; a < FMM; ++a) {
+      double cv5[4][FMN];
+      int64_t dr5[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + roff(a) + lr + 4 * r;
+        dr5[r] = (int64_t)(relpos[u.relrow_off + min(i, M - 1)] - u.d_row0) * u.d_ld;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) cv5[r][b] = D[dr5[r] + (dcol[b] >= 0 ? dcol[b] : 0)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + roff(a) + lr + 4 * r;
+        if (i >= M || a >= na) continue;
+#pragma unroll
+        for (int b = 0; b < FMN; ++b) {
+          const int j = j0 + coff(b) + lc;
+          if (dcol[b] >= 0 && (!u.lower || u.src_r0 + i >= u.src_c0 + j)) D[dr5[r] + dcol[b]] = cv5[r][b] - acc[a][b][r];
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int a = 0; a < FMM; ++a)
 #pragma unroll
@@ -1561,6 +1694,7 @@ __device__ __forceinline__ void update_body(const UpdTile tl, const UpdUnit& u,
         }
 #endif
       }
+#endif
   } else {
     double* D = L + u.d_off + (int64_t)u.d_row0 * u.d_ld + u.d_col0;
     // TRSM writes X in place, BUFFER stores the product into the scratch block: plain stores
@@ -2284,7 +2418,7 @@ void launch_chain_block(const LaunchSink& st, const ChainUnit* units, int64_t co
 void launch_trsm_rows(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
                       const double* dinv, int pw, int prio) {
   if (count <= 0) return;
-  const unsigned lds = (unsigned)(sizeof(double) * (4 * kTrsmRows + 2 * 64) * TLD);
+  const unsigned lds = (unsigned)(sizeof(double) * 2 * 64 * TLD);
   thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);

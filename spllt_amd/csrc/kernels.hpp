@@ -34,7 +34,7 @@ void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t co
 // diagonal block factored, the panels' inverses emitted
 void launch_chain_block(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
                         int* flag, int pw, const ChainUnit& unit0);
-// the rows below a chain block solved against it, 32 rows x all columns per workgroup (tiles: unit, ti)
+// the rows below a chain block solved against it, 64 rows x all columns per workgroup (tiles: unit, ti)
 void launch_trsm_rows(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,
                       const double* dinv, int pw, int prio);
 // one whole panel step per launch (PanelUnit; tiles: unit, ti = 64-row block below the panel)

@@ -799,12 +799,12 @@ struct Builder {
               fl += ft + fu;
             }
             if (blk4) {
-              // one workgroup per 32 rows and all columns of the chain block (k_trsm_rows)
+              // one workgroup per 64 rows and all columns of the chain block (k_trsm_rows)
               Launch L;
               L.kind = L_TRSM4;
               L.level = lev;
               L.first = (int64_t)P.tiles.size();
-              L.tile = 32;
+              L.tile = 64;
               L.flops = fl;
               L.stream = ST_CHAIN;
               L.record = evD;
@@ -814,7 +814,7 @@ struct Builder {
                 u.a_w = S.bcols[u.src_bcol0].width;
                 u.a_off = S.bcols[u.src_bcol0].off;
                 P.units.push_back(u);
-                for (int ti = 0; ti < cdiv(u.M, 32); ++ti) P.tiles.push_back(UpdTile{uid, (short)ti, 0});
+                for (int ti = 0; ti < cdiv(u.M, 64); ++ti) P.tiles.push_back(UpdTile{uid, (short)ti, 0});
               }
               L.count = (int64_t)P.tiles.size() - L.first;
               if (L.count > 0 || L.record >= 0) P.launches.push_back(L);   // (an empty launch still forwards the event)

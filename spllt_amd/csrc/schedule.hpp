@@ -138,7 +138,7 @@ enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, /*
 // L_CHAIN4 (k_chain_block): one workgroup factors the whole diagonal block of a CHAIN BLOCK of up to
 // four panels (ChainUnit with pn = its width <= 4 pw) and emits the panels' inverses (per panel, the
 // layout of the one-panel chain steps).
-// L_TRSM4 (k_trsm_rows): the rows below a chain block solved against it, one workgroup per 32 rows and
+// L_TRSM4 (k_trsm_rows): the rows below a chain block solved against it, one workgroup per 64 rows and
 // ALL the block's columns (tiles: unit, ti; TRSM-mode UpdUnits with N = K = the block's width).  The
 // two replace, per chain block, up to four POTRF, four TRSM and three in-panel update launches of the
 // chain stream.  (Round 3's two-panel chain blocks -- k_chain_potrf2, which emitted a 128 x 128
@@ -231,7 +231,7 @@ struct ScheduleOptions {
   int pw = 64;          // inner panel width (<= kPanelMax)
   int tile = 128;       // GEMM tile edge for large units
   int cb = 64;          // ignored (chain block of the removed sub-tile chain kernels)
-  bool chain4 = true;   // block-column steps whose block columns are wider than one panel: chain blocks of
+  bool chain4 = false;  // block-column steps whose block columns are wider than one panel: chain blocks of
                         // up to FOUR panels (L_CHAIN4 + L_TRSM4, two dependent launches per 4 pw columns of the
                         // panel chain instead of twelve); false (SPLLT_CHAIN4=0): one panel per chain step
   // multi-GPU subtree partition: node_owner[s] = owning rank of a pruned-subtree

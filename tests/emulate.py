@@ -190,8 +190,8 @@ def emulate_program(f, val, exchange=None, partitioned=False):
             u = units[int(t["unit"])]
             i0, j0 = int(t["ti"]) * T, int(t["tj"]) * T
             mi, nj = min(T, int(u["M"]) - i0), min(T, int(u["N"]) - j0)
-            if kind == 9:          # k_trsm_rows: 32 rows x ALL columns of the chain block per workgroup,
-                assert u["mode"] == MODE_TRSM and j0 == 0 and T == 32      # solved against its factored diagonal block
+            if kind == 9:          # k_trsm_rows: 64 rows x ALL columns of the chain block per workgroup,
+                assert u["mode"] == MODE_TRSM and j0 == 0 and T == 64      # solved against its factored diagonal block
                 cw, ld, off = int(u["N"]), int(u["d_ld"]), int(u["d_off"])
                 cs, rr = int(u["d_col0"]), int(u["d_row0"]) + i0
                 assert int(u["k0"]) == cs and int(u["klen"]) == cw and int(u["d_row0"]) == cs + cw

@@ -197,11 +197,11 @@ def _access_sets(f):
                 u = units[uid]
                 if kind == 9:
                     # k_trsm_rows also reads the factored diagonal block of its chain block, and every
-                    # 32-row block of the unit has its workgroup
+                    # 64-row block of the unit has its workgroup
                     b9, cs9, cw9 = bcol_of(u["d_off"]), int(u["d_col0"]), int(u["N"])
                     R.append((b9, cs9, cs9 + cw9, cs9, cs9 + cw9))
                     tl9 = tiles[first:first + count]
-                    assert sorted(tl9["ti"][tl9["unit"] == uid].tolist()) == list(range(-(-int(u["M"]) // 32)))
+                    assert sorted(tl9["ti"][tl9["unit"] == uid].tolist()) == list(range(-(-int(u["M"]) // 64)))
                 db = bcol_of(u["d_off"]) if u["mode"] != 3 else -1
                 M, N = int(u["M"]), int(u["N"])
                 for sg in range(int(u["nseg"])):
