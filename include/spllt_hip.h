@@ -277,6 +277,11 @@ const char *spllt_hip_last_error(const void *fkeep);
 int spllt_hip_last_flag(const void *fkeep);
 const char *spllt_hip_version(void);
 
+/* test hooks: "wedge" marks the HIP runtime as not having returned from a call (what the wait /
+ * submission deadlines do), "wedged" reads the mark (1 / 0), "teardown" runs the library's atexit
+ * handler now (it must touch nothing once the mark is set).  -1: unknown request. */
+int spllt_hip_debug(const char *what);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,7 +86,11 @@ typedef struct {
 void spllt_analyse(void **akeep, void **fkeep, spllt_options_t *options, int n, int *ptr,
                    int *row, spllt_inform_t *info, int *order);
 
-/* :68  (ciface:190-234)  asynchronous numerical factorization P A P^T = L L^T */
+/* :68  (ciface:190-234)  asynchronous numerical factorization P A P^T = L L^T.
+ * `val` must stay valid until spllt_wait returns (the reference reads it from its tasks, too).
+ * If the call comes back with flag -30 because the submission itself ran into its deadline (the
+ * HIP runtime did not return), `val` must stay valid for the rest of the process: the library's
+ * helper thread may still be reading it; the handle is dead and spllt_deallocate_fkeep leaks it. */
 void spllt_factor(void *akeep, void *fkeep, spllt_options_t *options, int nnz, double *val,
                   spllt_inform_t *info);
 

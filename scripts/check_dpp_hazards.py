@@ -49,6 +49,20 @@ def main():
                     print('  HAZARD', name[:40], ':', p, '->', l)
                     break
                 ws += 1
+        # transcendental result forwarding: the instruction right behind a v_rcp / v_rsq / v_sqrt_f64 must
+        # not read its destination (1 wait state; the inline assembly carries an s_nop 0 for it)
+        for i, l in enumerate(lines[:-1]):
+            if not re.match(r'v_(rcp|rsq|sqrt)_f64', l):
+                continue
+            dst = regs(l.split(None, 1)[1].split(',')[0])
+            nxt = lines[i + 1]
+            if nxt.startswith('v_') and len(nxt.split(None, 1)) > 1:
+                srcs = set()
+                for tok in nxt.split(None, 1)[1].split(',')[1:]:
+                    srcs |= regs(tok.strip().lstrip('-|').split()[0].rstrip('|')) if tok.strip() else set()
+                if dst & srcs:
+                    bad += 1
+                    print('  HAZARD (trans result forwarding)', name[:40], ':', l, '->', nxt)
         nfmac = sum('v_fmac_f64_dpp' in l for l in lines)
         nscr = sum('scratch_' in l for l in lines)
         print(f'{name[:60]}: {len(lines)} instructions, {ndpp} DPP ({nfmac} v_fmac_f64_dpp), {nscr} scratch accesses, {bad} hazards')

@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program", "spllt_hip_timeline",
     "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix", "spllt_hip_set_communicator",
-    "spllt_hip_last_flag",
+    "spllt_hip_last_flag", "spllt_hip_debug",
 ]
 
 _lib = None
@@ -77,6 +77,8 @@ def load():
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     opt, inf = C.POINTER(spllt_options_t), C.POINTER(spllt_inform_t)
     lib.spllt_analyse.argtypes = [vpp, vpp, opt, C.c_int, ip, ip, inf, ip]
+    lib.spllt_hip_debug.argtypes = [C.c_char_p]
+    lib.spllt_hip_debug.restype = C.c_int
     lib.spllt_analyse.restype = None
     lib.spllt_hip_analyse_ordered.argtypes = [vpp, vpp, opt, C.c_int, ip, ip, inf, ip, ip]
     lib.spllt_hip_analyse_ordered.restype = None

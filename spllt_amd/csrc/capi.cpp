@@ -461,9 +461,11 @@ void spllt_deallocate_fkeep(void** fkeep, int* stat) {
   }
   if (f->dead) {
     // a submission of this handle never returned: the helper thread may still be inside the
-    // engine (and reads the symbolic structure through it) -- both are leaked
-    (void)f->eng.release();
-    (void)new std::shared_ptr<Symbolic>(f->S);
+    // engine, and if it was merely slow it goes on to write f->eng and to read the symbolic
+    // structure and the staged values through f -- the whole handle is leaked, not just its parts
+    // (and `val` of the spllt_factor call that failed must stay valid: spllt_iface.h)
+    *fkeep = nullptr;
+    return;
   }
   delete f;
   *fkeep = nullptr;
@@ -580,6 +582,17 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 65536) f->eo.graph = 2;       // the DAG of the multi-stream program
   if (flags & 131072) f->eo.graph = 0;      // bit 17: eager launches
   return 0;
+}
+
+// test hooks of the process-wide "runtime is wedged" state (engine.cpp): "wedge" sets it, "wedged"
+// reads it, "teardown" runs the atexit handler of the pools now
+int spllt_hip_debug(const char* what) {
+  if (!what) return -1;
+  const std::string w(what);
+  if (w == "wedge") { mark_runtime_wedged(); return 0; }
+  if (w == "wedged") return runtime_wedged() ? 1 : 0;
+  if (w == "teardown") { run_pools_teardown_for_test(); return 0; }
+  return -1;
 }
 
 int spllt_hip_set_chain_block(void* fkeep, int chain_block) {
@@ -867,7 +880,12 @@ int spllt_hip_last_flag(const void* fkeep) {
 
 const char* spllt_hip_last_error(const void* fkeep) {
   const Fkeep* f = static_cast<const Fkeep*>(fkeep);
-  return f ? f->last_error.c_str() : "";
+  if (!f) return "";
+  // (a handle whose communicator is a one-rank stand-in says so for as long as it lives)
+  if (f->last_error.empty() && f->eng && f->eng->comm_rehearsal())
+    return "rehearsal: a one-rank communicator stands in for the partition's ranks (SPLLT_HIP_COMM_REHEARSAL); "
+           "the factor of this handle is not the factor of the matrix";
+  return f->last_error.c_str();
 }
 
 const char* spllt_hip_version(void) { return "spllt-hip 0.1 (gfx950)"; }

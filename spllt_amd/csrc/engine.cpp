@@ -111,6 +111,12 @@ struct PinBuf { void* p; size_t bytes; };
 std::vector<PinBuf> g_pin_cache;
 bool g_teardown_registered = false;
 void pools_teardown();
+// Process-wide: a wait ran into its deadline or a submission never returned.  From then on the
+// HIP runtime may be stuck inside a call that holds its own locks (or ours): nothing at exit may
+// touch it again -- pools_teardown() returns at once, so that the process that DETECTED the hang
+// can still exit (its exit code tells the caller), instead of trading "the call never returns"
+// for "the process never exits".
+std::atomic<bool> g_runtime_wedged{false};
 void register_teardown() {
   if (!g_teardown_registered) {
     g_teardown_registered = true;
@@ -126,9 +132,12 @@ size_t dev_cache_cap() {
 }
 }  // namespace
 
-// a device buffer of at least `bytes`: from the cache (smallest fit that wastes at most half), else hipMalloc
-static hipError_t dev_alloc(void** p, size_t bytes, int device) {
+// a device buffer of at least `bytes`: from the cache (smallest fit that wastes at most half), else
+// hipMalloc; *cap receives the buffer's real capacity (what dev_release must be told, so that the
+// cache's byte count -- and with it the SPLLT_HIP_CACHE_MB cap -- stays exact)
+static hipError_t dev_alloc(void** p, size_t bytes, int device, size_t* cap) {
   bytes = std::max<size_t>(bytes, 256);
+  *cap = bytes;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     register_teardown();
@@ -140,6 +149,7 @@ static hipError_t dev_alloc(void** p, size_t bytes, int device) {
     }
     if (best >= 0) {
       *p = g_dev_cache[(size_t)best].p;
+      *cap = g_dev_cache[(size_t)best].bytes;
       g_dev_cached_bytes -= g_dev_cache[(size_t)best].bytes;
       g_dev_cache.erase(g_dev_cache.begin() + best);
       return hipSuccess;
@@ -209,6 +219,7 @@ int Engine::wait_event(hipEvent_t ev, const char* what) {
   status_ = kErrHip;
   err_ = std::string(what) + ": the copy engine did not finish within " + std::to_string((int)limit_s) + " s";
   poisoned_ = true;
+  mark_runtime_wedged();
   std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
   return kErrHip;
 }
@@ -285,13 +296,15 @@ int Engine::sync_stream(hipStream_t st, const char* what) {
   // touched again -- no further synchronisation (it would block for good), and its streams,
   // events, pinned words and device buffers are neither reused nor freed (see ~Engine).
   poisoned_ = true;
+  mark_runtime_wedged();
   std::fprintf(stderr, "spllt-hip: %s\n", err_.c_str());
   return kErrHip;
 }
 
 hipError_t Engine::dalloc(void** p, size_t bytes) {
-  hipError_t e = dev_alloc(p, bytes, device_);
-  if (e == hipSuccess) owned_.push_back({*p, std::max<size_t>(bytes, 256)});
+  size_t cap = 0;
+  hipError_t e = dev_alloc(p, bytes, device_, &cap);
+  if (e == hipSuccess) owned_.push_back({*p, cap});
   return e;
 }
 
@@ -490,8 +503,17 @@ void pools_teardown() {
   // and they run under a timeout.
   static const int mode = [] { const char* e = std::getenv("SPLLT_TEARDOWN"); return e ? std::atoi(e) : 1; }();
   if (mode == 0) return;
+  if (g_runtime_wedged.load()) {
+    crumb("teardown: skipped, the runtime is wedged");
+    return;
+  }
   crumb("teardown: streams (lock)");
-  std::lock_guard<std::mutex> lk(g_stream_mu);
+  // (a helper thread stuck inside borrow_streams / hipExtStreamCreateWithCUMask holds this mutex for good)
+  std::unique_lock<std::mutex> lk(g_stream_mu, std::try_to_lock);
+  if (!lk.owns_lock()) {
+    crumb("teardown: skipped, the stream pool is locked");
+    return;
+  }
   for (StreamSet& ss : g_stream_pool) {
     if (mode < 2) break;
     if (ss.in_use) continue;
@@ -1039,8 +1061,18 @@ int Engine::set_communicator(void* nccl_comm) {
   // SPLLT_HIP_COMM_REHEARSAL=1: a communicator smaller than the partition is accepted (one-GPU
   // rehearsal of the call sequence: the sums then miss the other ranks' parts, broadcast roots
   // are taken modulo its size)
-  static const bool rehearsal = std::getenv("SPLLT_HIP_COMM_REHEARSAL") != nullptr;
-  if ((cnt != opt_.nranks || rk != opt_.rank) && !rehearsal) {
+  // -- accepted only for a ONE-rank communicator (the one-GPU test of the call sequence), announced
+  // on stderr, and remembered: spllt_hip_last_error says so for as long as the handle lives.
+  static const bool rehearsal_env = std::getenv("SPLLT_HIP_COMM_REHEARSAL") != nullptr;
+  const bool mismatch = cnt != opt_.nranks || rk != opt_.rank;
+  const bool rehearsal = rehearsal_env && cnt == 1;
+  if (mismatch && rehearsal) {
+    comm_rehearsal_ = true;
+    std::fprintf(stderr, "spllt-hip: WARNING: SPLLT_HIP_COMM_REHEARSAL: a one-rank communicator stands in for rank %d of %d "
+                         "-- the collectives run, the factor of this handle is NOT the factor of the matrix\n",
+                 opt_.rank, opt_.nranks);
+  }
+  if (mismatch && !rehearsal) {
     err_ = "spllt_hip_set_communicator: the communicator is rank " + std::to_string(rk) + " of " + std::to_string(cnt) +
            ", the partition (spllt_hip_set_partition) is rank " + std::to_string(opt_.rank) + " of " +
            std::to_string(opt_.nranks);
@@ -1080,7 +1112,11 @@ int Engine::collective(const Exchange& E) {
                              comm_, stream_), "ncclReduceScatter");
   } else if (E.kind == X_BCAST) {
     // one broadcast per root (the items of a root are contiguous in the buffer), as one group
+    // (a failed broadcast does not leave the group open: ncclGroupEnd is always reached -- the
+    // communicator would stay in group mode and the other ranks in the collective -- and the first
+    // error is reported afterwards)
     NCCLCHK(R.group_start(), "ncclGroupStart");
+    int first_err = 0;
     for (int i = E.first_item; i < E.first_item + E.nitems;) {
       const ExchangeItem& a = prog_.xitems[(size_t)i];
       int64_t cnt = 0;
@@ -1088,11 +1124,14 @@ int Engine::collective(const Exchange& E) {
       for (; j < E.first_item + E.nitems && prog_.xitems[(size_t)j].root == a.root &&
              prog_.xitems[(size_t)j].xoff == a.xoff + cnt; ++j)
         cnt += prog_.xitems[(size_t)j].count;
-      NCCLCHK(R.broadcast(xbuf_ + a.xoff, xbuf_ + a.xoff, (size_t)cnt, kNcclDouble, a.root % comm_size_, comm_, stream_),
-              "ncclBroadcast");
+      const int r = R.broadcast(xbuf_ + a.xoff, xbuf_ + a.xoff, (size_t)cnt, kNcclDouble, a.root % comm_size_, comm_,
+                                stream_);
+      if (r != 0 && first_err == 0) first_err = r;
       i = j;
     }
-    NCCLCHK(R.group_end(), "ncclGroupEnd");
+    const int rend = R.group_end();
+    NCCLCHK(first_err, "ncclBroadcast");
+    NCCLCHK(rend, "ncclGroupEnd");
   }
   return 0;
 }
@@ -1460,6 +1499,10 @@ SubmitWorker& submit_worker() {
 }
 }  // namespace
 
+void mark_runtime_wedged() { g_runtime_wedged.store(true); }
+bool runtime_wedged() { return g_runtime_wedged.load(); }
+void run_pools_teardown_for_test() { pools_teardown(); }
+
 int run_with_deadline(std::function<int()> fn, std::string* why) {
   // (SPLLT_HIP_SUBMIT_TIMEOUT_S: a deadline of its own -- a wait may legitimately be given a few
   // milliseconds by a caller that polls, engine creation may not)
@@ -1490,6 +1533,7 @@ int run_with_deadline(std::function<int()> fn, std::string* why) {
   std::unique_lock<std::mutex> lk(job->mu);
   if (job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) return job->rc;
   w.wedged.store(true);
+  mark_runtime_wedged();
   if (why)
     *why = std::string("submission did not return within ") + std::to_string((int)limit_s) + " s; last step: " +
            last_crumb();

@@ -22,6 +22,11 @@ double hip_deadline_s();
 // does not come back makes this call and every later one return SPLLT_ERROR_HIP (-30) with *why
 // naming the last step the library reached (engine.cpp)
 int run_with_deadline(std::function<int()> fn, std::string* why);
+// process-wide "the HIP runtime did not come back from a call" flag (set by the wait / submission
+// deadlines): the atexit teardown of the pools then touches nothing
+void mark_runtime_wedged();
+bool runtime_wedged();
+void run_pools_teardown_for_test();
 const char* last_crumb();
 
 struct EngineOptions {
@@ -68,6 +73,7 @@ class Engine {
 
   int status() const { return status_; }  // 0 or SPLLT error flag from construction
   bool poisoned() const { return poisoned_; }
+  bool comm_rehearsal() const { return comm_rehearsal_; }
   void poison(const std::string& why) { poisoned_ = true; status_ = -30; err_ = why; }
   const std::string& error() const { return err_; }
 
@@ -173,6 +179,7 @@ class Engine {
   int stage_val(const double* val_host, int64_t nnz);
   int wait_event(hipEvent_t ev, const char* what);
   bool poisoned_ = false;   // a wait ran into its deadline: see ~Engine
+  bool comm_rehearsal_ = false;   // set_communicator accepted a one-rank stand-in (SPLLT_HIP_COMM_REHEARSAL): results are not the factor
   mutable bool localize_failed_ = false;
   int graph_mode_ = 0;
   hipGraph_t graph_ = nullptr;

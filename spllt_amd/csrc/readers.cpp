@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -38,18 +39,28 @@ struct SplitMix {
 struct Coo {
   int i, j;      // 0-based, i >= j (lower)
   double v;
+  char up = 0;   // the file listed the entry above the diagonal (MatrixMarket symmetric files)
 };
 
 // lower-triangular entries (duplicates summed) -> 1-based CSC with sorted rows; values = 3: every
 // diagonal entry becomes 1 + sum |off-diagonal entries of its row of the full symmetric matrix|
+// reject_mirrored: an off-diagonal entry listed once below and once above the diagonal (a "symmetric"
+// file that stores both triangles) is an error instead of a sum of the two
 int finish(int n, std::vector<Coo>& e, int values, int* n_out, int* nnz_out, int** ptr_out, int** row_out,
-           double** val_out) {
-  std::sort(e.begin(), e.end(), [](const Coo& a, const Coo& b) { return a.j != b.j ? a.j < b.j : a.i < b.i; });
+           double** val_out, bool reject_mirrored = false) {
+  std::stable_sort(e.begin(), e.end(), [](const Coo& a, const Coo& b) { return a.j != b.j ? a.j < b.j : a.i < b.i; });
   std::vector<Coo> u;
   u.reserve(e.size() + (size_t)n);
   for (const Coo& c : e) {
-    if (!u.empty() && u.back().i == c.i && u.back().j == c.j) u.back().v += c.v;
-    else u.push_back(c);
+    if (!u.empty() && u.back().i == c.i && u.back().j == c.j) {
+      if (reject_mirrored && c.i != c.j && u.back().up != c.up) {
+        std::fprintf(stderr, "spllt-hip: symmetric file lists entry (%d, %d) in both triangles\n", c.i + 1, c.j + 1);
+        return SPLLT_ERROR_PARAMETER;
+      }
+      u.back().v += c.v;
+    } else {
+      u.push_back(c);
+    }
   }
   if (values == 3) {
     std::vector<double> rs((size_t)n, 0.0);
@@ -63,7 +74,7 @@ int finish(int n, std::vector<Coo>& e, int values, int* n_out, int* nnz_out, int
       if (c.i == c.j) c.v = 1.0 + rs[(size_t)c.i];
     bool missing = false;
     for (int k = 0; k < n; ++k)
-      if (!has[(size_t)k]) { u.push_back(Coo{k, k, 1.0 + rs[(size_t)k]}); missing = true; }
+      if (!has[(size_t)k]) { u.push_back(Coo{k, k, 1.0 + rs[(size_t)k], 0}); missing = true; }
     if (missing)
       std::sort(u.begin(), u.end(), [](const Coo& a, const Coo& b) { return a.j != b.j ? a.j < b.j : a.i < b.i; });
   }
@@ -109,6 +120,8 @@ bool read_fixed(const std::vector<std::string>& lines, size_t pos, size_t nlines
   int per = 0, width = 0;
   if (!fortran_fields(fmt, per, width)) return false;
   out.clear();
+  // (the header's counts are claims: never more than the lines that are really there can hold)
+  if (pos > lines.size() || nlines > lines.size() - pos || count > nlines * (size_t)per) return false;
   out.reserve(count);
   for (size_t l = pos; l < pos + nlines && l < lines.size(); ++l) {
     const std::string& ln = lines[l];
@@ -139,12 +152,27 @@ std::string lower(std::string s) {
   return s;
 }
 
+// (the C boundary lets no C++ exception through: a header that promises more than memory holds, or
+// anything else that throws, is an error flag, not std::terminate)
+template <class F>
+int guarded(const char* path, F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    std::fprintf(stderr, "spllt-hip: %s: out of memory while reading\n", path ? path : "(null)");
+    return SPLLT_ERROR_ALLOCATION;
+  } catch (...) {
+    std::fprintf(stderr, "spllt-hip: %s: malformed file\n", path ? path : "(null)");
+    return SPLLT_ERROR_PARAMETER;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int spllt_hip_read_rb(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
-                      double** val) {
+static int read_rb_impl(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
+                        double** val) {
   if (!path || !n || !nnz || !ptr || !row || !val || (values != 0 && values != 3)) return SPLLT_ERROR_PARAMETER;
   bool ok = false;
   std::vector<std::string> lines = read_lines(path, ok);
@@ -164,6 +192,11 @@ int spllt_hip_read_rb(const char* path, int values, int seed, int* n, int* nnz, 
     std::istringstream is(lines[2]);
     is >> mxtype >> nrow >> ncol >> ne;
     mxtype = lower(mxtype);
+  }
+  if (nrow > INT32_MAX || ne > INT32_MAX || totcrd < 0 || ptrcrd < 0 || indcrd < 0 || valcrd < -1 ||
+      (size_t)ptrcrd > lines.size() || (size_t)indcrd > lines.size() || (valcrd > 0 && (size_t)valcrd > lines.size())) {
+    std::fprintf(stderr, "spllt-hip: %s: header counts out of range\n", path);
+    return SPLLT_ERROR_PARAMETER;
   }
   if (mxtype.size() != 3 || mxtype[1] != 's' || mxtype[2] != 'a' || nrow != ncol || nrow <= 0 || ne < 0) {
     std::fprintf(stderr, "spllt-hip: %s: only assembled symmetric matrices (?sa) are supported, got '%s'\n", path,
@@ -205,14 +238,19 @@ int spllt_hip_read_rb(const char* path, int values, int seed, int* n, int* nnz, 
       const long i = ri[(size_t)k] - 1;
       if (i < 0 || i >= nrow) return SPLLT_ERROR_PARAMETER;
       if (i < j) continue;                      // the stored triangle is the lower one; anything above is dropped
-      e.push_back(Coo{(int)i, (int)j, v[(size_t)k]});
+      e.push_back(Coo{(int)i, (int)j, v[(size_t)k], 0});
     }
   }
   return finish((int)nrow, e, values, n, nnz, ptr, row, val);
 }
 
-int spllt_hip_read_mm(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
+int spllt_hip_read_rb(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
                       double** val) {
+  return guarded(path, [&] { return read_rb_impl(path, values, seed, n, nnz, ptr, row, val); });
+}
+
+static int read_mm_impl(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
+                        double** val) {
   if (!path || !n || !nnz || !ptr || !row || !val || (values != 0 && values != 3)) return SPLLT_ERROR_PARAMETER;
   std::ifstream in(path);
   if (!in) {
@@ -238,6 +276,21 @@ int spllt_hip_read_mm(const char* path, int values, int seed, int* n, int* nnz, 
   {
     std::istringstream is(ln);
     if (!(is >> m >> nc >> ne) || m != nc || m <= 0 || ne < 0) return SPLLT_ERROR_PARAMETER;
+    if (m > INT32_MAX || ne > INT32_MAX) {      // (the reference's C-ABI: int n, int nnz)
+      std::fprintf(stderr, "spllt-hip: %s: size line %ld %ld %ld beyond the 32-bit interface\n", path, m, nc, ne);
+      return SPLLT_ERROR_PARAMETER;
+    }
+  }
+  // an entry takes at least four bytes ("1 1\n"): the header cannot promise more than the file holds
+  {
+    const std::streampos here = in.tellg();
+    in.seekg(0, std::ios::end);
+    const std::streampos end = in.tellg();
+    in.seekg(here);
+    if (here >= 0 && end >= here && (long long)ne > ((long long)(end - here) + 3) / 4) {
+      std::fprintf(stderr, "spllt-hip: %s: the size line promises %ld entries, the file is too short for them\n", path, ne);
+      return SPLLT_ERROR_PARAMETER;
+    }
   }
   const bool pattern = field == "pattern";
   if (pattern && values == 0) {
@@ -258,9 +311,14 @@ int spllt_hip_read_mm(const char* path, int values, int seed, int* n, int* nnz, 
     // symmetric: the entry stands for both triangles; general: A := (A + A^T) / 2, i.e. every
     // off-diagonal entry contributes half to the lower-triangular position of its pair
     const double w = (symm == "general" && i != j) ? 0.5 * x : x;
-    e.push_back(Coo{(int)std::max(i, j), (int)std::min(i, j), w});
+    e.push_back(Coo{(int)std::max(i, j), (int)std::min(i, j), w, (char)(i < j)});
   }
-  return finish((int)m, e, values, n, nnz, ptr, row, val);
+  return finish((int)m, e, values, n, nnz, ptr, row, val, symm == "symmetric");
+}
+
+int spllt_hip_read_mm(const char* path, int values, int seed, int* n, int* nnz, int** ptr, int** row,
+                      double** val) {
+  return guarded(path, [&] { return read_mm_impl(path, values, seed, n, nnz, ptr, row, val); });
 }
 
 void spllt_hip_free_matrix(int* ptr, int* row, double* val) {

@@ -116,3 +116,31 @@ def test_analyse_rejects_tile_sizes_beyond_the_kernel_limit():
         api.Factorization(3, ptr, row, nb=2048)
     assert ei.value.flag == -98
     assert api.Factorization(3, ptr, row, nb=1024).sym_info()["n"] == 3
+
+
+def test_wedged_runtime_makes_the_exit_handler_touch_nothing(tmp_path):
+    """The wait / submission deadlines mark the HIP runtime as wedged, process-wide; from then on the
+    library's atexit handler (events, pinned memory, cached device buffers: hipFree synchronises the
+    whole device) must return at once, so that the process that detected a hang can still exit.
+    Checked through the test hooks, in a process of its own: the handler's breadcrumbs say what it did."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    crumbs = tmp_path / "crumbs.txt"
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from spllt_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "assert lib.spllt_hip_debug(b'wedged') == 0 and lib.spllt_hip_debug(b'nonsense') == -1\n"
+        "lib.spllt_hip_debug(b'teardown')\n"
+        "print('FIRST', open(%r).read().strip())\n"
+        "assert lib.spllt_hip_debug(b'wedge') == 0 and lib.spllt_hip_debug(b'wedged') == 1\n"
+        "lib.spllt_hip_debug(b'teardown')\n"
+        "print('SECOND', open(%r).read().strip())\n"
+    ) % (root, str(crumbs), str(crumbs))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, SPLLT_HIP_CRUMBS=str(crumbs)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FIRST teardown: done" in r.stdout, r.stdout
+    assert "SECOND teardown: skipped, the runtime is wedged" in r.stdout, r.stdout

@@ -142,3 +142,53 @@ def test_c_reader_feeds_the_c_api(tmp_path):
     f = api.Factorization(n, ptr.astype(np.int32), row.astype(np.int32), nb=16, nemin=4)
     assert f.sym_info()["n"] == 80 and f.sym_info()["nnz_a"] == val.size
     f.close()
+
+
+@pytest.mark.parametrize("body,why", [
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3 4000000000000\n1 1 2.0\n", "count beyond the 32-bit interface"),
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3 2000000000\n1 1 2.0\n", "count the file is too short for"),
+    ("%%MatrixMarket matrix coordinate real symmetric\n4000000000 4000000000 1\n1 1 2.0\n", "n beyond int"),
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3 3\n1 1 2.0\n2 1 1.0\n1 2 1.0\n", "both triangles of a symmetric file"),
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3 2\n1 1 2.0\n4 1 1.0\n", "row index out of range"),
+    ("%%MatrixMarket matrix coordinate real symmetric\n3 3 2\n1 1 2.0\n", "fewer entries than promised"),
+])
+def test_c_reader_mm_malformed_files_set_a_flag(tmp_path, body, why):
+    """Header counts are claims, not facts: a size line that promises more than the file (or the
+    32-bit interface) holds, an index out of range, or a symmetric file that lists an entry in
+    both triangles comes back as an error flag -- never as std::terminate from a reserve(), and
+    never as a silently doubled entry."""
+    path = tmp_path / "bad.mtx"
+    path.write_text(body)
+    with pytest.raises(ValueError, match="flag -1"):      # -10 (parameter) or -1 (allocation)
+        matgen.read_file_c(str(path), "mm", values=0)
+
+
+def test_c_reader_mm_upper_triangle_only_is_mirrored(tmp_path):
+    """a symmetric file that stores the UPPER triangle (some writers do) is read as its mirror;
+    repeated entries of the same triangle are summed (assembled finite-element files)"""
+    path = tmp_path / "upper.mtx"
+    path.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 5\n1 1 2.0\n1 2 1.0\n1 2 0.5\n2 2 3.0\n3 3 4.0\n")
+    n, ptr, row, val = matgen.read_file_c(str(path), "mm", values=0)
+    assert n == 3 and list(ptr) == [1, 3, 4, 5] and list(row) == [1, 2, 2, 3]
+    np.testing.assert_array_equal(val, [2.0, 1.5, 3.0, 4.0])
+
+
+def test_c_reader_rb_header_counts_are_checked(tmp_path):
+    """a Rutherford-Boeing header whose card / entry counts exceed the file is an error flag"""
+    path = tmp_path / "bad.rb"
+    with open(path, "w") as fh:
+        fh.write(f"{'bad header':<72}{'KEY':<8}\n")
+        fh.write(f"{3:14d}{1:14d}{1:14d}{1:14d}\n")
+        fh.write(f"{'rsa':<14}{3:14d}{3:14d}{2000000000:14d}{0:14d}\n")
+        fh.write(f"{'(4I2)':<16}{'(5I2)':<16}{'(5E10.3)':<20}\n")
+        fh.write(" 1 3 5 6\n 1 2 2 3 3\n 2.000E+00-1.000E+00 2.000E+00-1.000E+00 2.000E+00\n")
+    with pytest.raises(ValueError, match="flag -10"):
+        matgen.read_file_c(str(path), "rb", values=0)
+    with open(path, "w") as fh:
+        fh.write(f"{'bad header':<72}{'KEY':<8}\n")
+        fh.write(f"{3000000:14d}{1000000:14d}{1000000:14d}{1000000:14d}\n")
+        fh.write(f"{'rsa':<14}{3:14d}{3:14d}{5:14d}{0:14d}\n")
+        fh.write(f"{'(4I2)':<16}{'(5I2)':<16}{'(5E10.3)':<20}\n")
+        fh.write(" 1 3 5 6\n 1 2 2 3 3\n 2.000E+00-1.000E+00 2.000E+00-1.000E+00 2.000E+00\n")
+    with pytest.raises(ValueError, match="flag -10"):
+        matgen.read_file_c(str(path), "rb", values=0)
