@@ -231,47 +231,91 @@ void prune_tree(Symbolic& S, int nth) {
   }
 }
 
-// Proportional mapping of the assembly tree onto `nranks` ranks: a set of sibling
-// subtrees that shares a range of ranks is split into two groups whose weights
-// follow the split of the range; a group that reaches a single rank belongs to it
-// completely (its separators included, so whole branches stay rank-local); a node
-// whose subtree still spans several ranks is top tree (-1, replicated).  Compared
-// with dealing the pruned subtrees of spllt_prune_tree to ranks by weight alone
-// this keeps the top tree - replicated work and exchange volume - minimal.
+// Modelled time of one node on one MI355X (seconds): its flops at the rate the update kernels reach
+// at its K (= its width; sustained 64-tile figures, DESIGN section 4: 28 / 40 / 50 / 58 / 62 TFLOP/s
+// at K = 64 ... 1024, i.e. ~68 K / (K + 90)) plus the scatter-add of its generated element at the
+// chip's rate for fp64 atomics (262 G adds/s).  The leaves of a nested-dissection
+// tree run at a tenth of the rate of the separators near the top: mapping subtrees by flops alone
+// gave the rank with the bushier half 30 % more time (flan_like, w = 2: 409 vs 316 ms).
+static double node_time(const Symbolic& S, int s) {
+  const double m = S.nrow(s), n = S.ncol(s);
+  double fl = 0;
+  for (int j = 1; j <= (int)n; ++j) fl += (m - n + j) * (m - n + j);
+  const double rate = 68e12 * n / (n + 90.0);
+  return fl / rate + 0.5 * (m - n) * (m - n) / 262e9;
+}
+
+// Mapping of the assembly tree onto `nranks` ranks: whole subtrees per rank, the nodes above them
+// are the top tree (-1).  The subtree roots start as the children of the virtual root; the largest
+// root of the most loaded rank is replaced by its children (it joins the top tree) and the roots are
+// dealt again, largest first to the least loaded rank, until the loads are balanced to 0.9 -- what
+// spllt_prune_tree does with its subtrees (reference src/spllt_analyse_mod.F90:806-987, the 0.9 at
+// :895-897) -- or the roots get too small to matter.  Loads are MODELLED TIMES (node_time), not
+// flops (SPLLT_OWNER_MODEL=flops: the symbolic flop count, the round-3 behaviour of the weights).
 void assign_owners(const Symbolic& S, int nranks, std::vector<int>& owner) {
   const int nn = S.nnodes;
   owner.assign(nn, -1);
   if (nranks < 1) nranks = 1;
   std::vector<std::vector<int>> kids(nn + 1);
   for (int s = 0; s < nn; ++s) kids[std::min(S.sparent[s], nn)].push_back(s);
-  struct Job { std::vector<int> nodes; int r0, r1; };
-  std::vector<Job> stack;
-  stack.push_back(Job{kids[nn], 0, nranks});
-  while (!stack.empty()) {
-    Job j = std::move(stack.back());
-    stack.pop_back();
-    // a single node over several ranks is top tree: descend to its children
-    while (j.r1 - j.r0 > 1 && j.nodes.size() == 1 && !kids[j.nodes[0]].empty())
-      j.nodes = kids[j.nodes[0]];   // owner stays -1
-    if (j.nodes.empty()) continue;
-    if (j.r1 - j.r0 == 1 || j.nodes.size() == 1) {
-      for (int r : j.nodes)
-        for (int v = S.least_desc[r]; v <= r; ++v) owner[v] = j.r0;
-      continue;
+  const char* model = std::getenv("SPLLT_OWNER_MODEL");
+  const bool by_flops = model && std::string(model) == "flops";
+  // subtree loads (postorder: children before parents)
+  std::vector<double> load(nn + 1, 0.0);
+  for (int s = 0; s < nn; ++s) {
+    if (by_flops) {
+      load[s] = (double)S.weight[s];     // (already the sum over the subtree)
+    } else {
+      load[s] += node_time(S, s);
+      load[std::min(S.sparent[s], nn)] += load[s];
     }
-    std::stable_sort(j.nodes.begin(), j.nodes.end(),
-                     [&](int a, int b) { return S.weight[a] > S.weight[b]; });
-    const int rh = (j.r1 - j.r0) / 2;
-    const double tl = (double)rh, tr = (double)(j.r1 - j.r0 - rh);   // rank shares of the two groups
-    Job L{{}, j.r0, j.r0 + rh}, R{{}, j.r0 + rh, j.r1};
-    double wl = 0, wr = 0;
-    for (int r : j.nodes) {
-      if (wl / tl <= wr / tr) { L.nodes.push_back(r); wl += (double)S.weight[r]; }
-      else { R.nodes.push_back(r); wr += (double)S.weight[r]; }
-    }
-    stack.push_back(std::move(L));
-    stack.push_back(std::move(R));
   }
+  double total = 0;
+  for (int r : kids[nn]) total += load[r];
+  std::vector<int> roots = kids[nn];
+  std::vector<int> where;
+  std::vector<double> rl;
+  auto deal = [&]() {
+    std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return load[a] > load[b]; });
+    where.assign(roots.size(), 0);
+    rl.assign((size_t)nranks, 0.0);
+    for (size_t i = 0; i < roots.size(); ++i) {
+      int best = 0;
+      for (int r = 1; r < nranks; ++r)
+        if (rl[(size_t)r] < rl[(size_t)best]) best = r;
+      where[i] = best;
+      rl[(size_t)best] += load[roots[i]];
+    }
+  };
+  const double min_piece = total / (64.0 * nranks);      // roots below this stay whole
+  for (int it = 0; it < 64 * nranks; ++it) {
+    deal();
+    if (nranks == 1) break;
+    int rmax = 0;
+    double lo = rl[0];
+    for (int r = 0; r < nranks; ++r) {
+      if (rl[(size_t)r] > rl[(size_t)rmax]) rmax = r;
+      lo = std::min(lo, rl[(size_t)r]);
+    }
+    if ((int)roots.size() >= nranks && lo >= 0.9 * rl[(size_t)rmax]) break;
+    // the largest root of the most loaded rank that can be split (with fewer roots than ranks: the largest of all)
+    int pick = -1;
+    for (size_t i = 0; i < roots.size(); ++i) {
+      if ((int)roots.size() >= nranks && where[i] != rmax) continue;
+      if (kids[roots[i]].empty() || load[roots[i]] < min_piece) continue;
+      if (pick < 0 || load[roots[i]] > load[roots[(size_t)pick]]) pick = (int)i;
+    }
+    if (pick < 0) break;
+    const int top = roots[(size_t)pick];
+    roots.erase(roots.begin() + pick);
+    for (int c : kids[top]) roots.push_back(c);             // `top` joins the top tree (owner stays -1)
+  }
+  if (nranks == 1) {
+    std::fill(owner.begin(), owner.end(), 0);
+    return;
+  }
+  for (size_t i = 0; i < roots.size(); ++i)
+    for (int v = S.least_desc[roots[i]]; v <= roots[i]; ++v) owner[v] = where[i];
 }
 
 int analyse(int n, const int64_t* ptr, const int* row, const int* user_order,
