@@ -80,6 +80,43 @@ def run_exchange(xbuf, step, rank, world, group=None, scratch=None, force=False)
     return xbuf
 
 
+class _NcclUniqueId(__import__("ctypes").Structure):
+    _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+
+
+def make_rccl_communicator(rank, world, group=None):
+    """An ncclComm_t of this process's own librccl (the copy torch loaded), for
+    spllt_hip_set_communicator -- what a C or Fortran caller of the library would hand over (the
+    reference keeps its distributed hook inside the library too, src/PaRSEC/spllt_parsec_blk_data.c:33-64).
+    Rank 0 draws the unique id, the process group (any backend) ships its 128 bytes, every rank
+    calls ncclCommInitRank.  Returns (comm handle as int, destroy function)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    uid = _NcclUniqueId()
+    if rank == 0:
+        rc = rccl.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId failed: {rc}")
+    if world > 1:
+        box = [bytes(uid.internal) if rank == 0 else None]       # (c_char array: raw bytes, zeros included)
+        if rank == 0:
+            box = [C.string_at(C.addressof(uid), 128)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.addressof(uid), box[0], 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank({world}, rank {rank}) failed: {rc}")
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+
+    def destroy():
+        rccl.ncclCommDestroy(comm)
+    return comm.value, destroy
+
+
 class DistributedFactorization:
     """Factorization of one pattern on `world` GPUs (this process = `rank` of
     the process group `group`).  world == 1 is the plain single-GPU engine.
@@ -87,11 +124,22 @@ class DistributedFactorization:
     distributed over the ranks / replicated on every rank."""
 
     def __init__(self, n, ptr, row, nb, rank, world, order=None, nemin=32, panel_width=None,
-                 group=None, dist_top=None, engine_flags=0):
+                 group=None, dist_top=None, engine_flags=0, driver=None, comm=None):
+        """driver: "library" -- the exchanges run INSIDE libspllt_hip.so on an ncclComm_t
+        (spllt_hip_set_communicator: the path a C / Fortran caller of the unchanged spllt_iface.h
+        gets; `comm` = an existing ncclComm_t handle, else one is created over the process group) --
+        or "python" -- this module drives them through torch.distributed (the gloo rehearsals and
+        CPU tests need that: RCCL has no two ranks on one device).  Default: "library" when the
+        process group's backend is nccl, unless SPLLT_MG_DRIVER says otherwise."""
         import torch
         import torch.distributed as dist
         from . import api
         self.rank, self.world, self.group = rank, world, group
+        if driver is None:
+            driver = os.environ.get("SPLLT_MG_DRIVER") or (
+                "library" if (world > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl") else "python")
+        self.driver = driver if world > 1 or comm is not None else "python"
+        self._comm_destroy = None
         if dist_top is not None:
             engine_flags |= 8192 if dist_top else 16384
         self.f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=world > 1,
@@ -111,6 +159,11 @@ class DistributedFactorization:
             if chunk:
                 self.scratch = torch.empty(chunk, dtype=torch.float64, device="cuda")
         self.dist_top = any(st[0] == X_REDUCE_OWNER for st in self.plan)
+        if self.driver == "library":
+            # the library owns the exchange buffer and runs every collective itself, on its own stream
+            if comm is None:
+                comm, self._comm_destroy = make_rccl_communicator(rank, world, group)
+            self.f.set_communicator(comm)
         self.stream_ordered = (world > 1 and dist.is_initialized() and
                                (dist.get_backend(group) == "nccl" or
                                 bool(os.environ.get("SPLLT_FORCE_STREAM_ORDERED"))))   # (tests: gloo)
@@ -141,6 +194,12 @@ class DistributedFactorization:
         self.f.factor_dev(dval.data_ptr())
         t1 = t2 = t0
         nx = 0
+        if self.driver == "library":
+            # (every exchange was issued inside spllt_hip_factor_dev; the phases are not separable here)
+            self.f.wait()
+            t3 = time.perf_counter()
+            self.phase_ms = {"total": (t3 - t0) * 1e3, "driver": "library (spllt_hip_set_communicator)"}
+            return self
         while True:
             k = self.f.pending_exchange()
             if k < 0:
@@ -211,6 +270,9 @@ class DistributedFactorization:
 
     def close(self):
         self.f.close()
+        if self._comm_destroy is not None:
+            self._comm_destroy()
+            self._comm_destroy = None
 
 
 def _timed(df, dval, steps, active):
@@ -314,6 +376,7 @@ def bench_distributed(args, A, n, ptr, row, val, order, nb, name, rank, world, r
                                        "(extend-add) on the engine's stream, replicated top tree")},
             "roofline": roof, "cpu_baseline": None,
             "detail": {"partition_width": w, "width_trials_ms": trial, "distributed_top_tree": df.dist_top,
+                       "exchange_driver": df.driver,
                        "exchanges": len(df.plan),
                        "phase_ms_rank0": df.phase_ms, "exchange_MB": df.xelems * 8 / 1e6,
                        "subtree_gflop_per_rank": (own_w / 1e9).round(1).tolist(),

@@ -272,6 +272,63 @@ def test_exchanges_inside_the_library_on_rccl_single_rank(top):
     assert finite and err <= 1e-12, ret[0]
 
 
+def _library_driver_worker(rank, world, port, ret):
+    """one process, one GPU, a ONE-rank nccl process group: DistributedFactorization with the
+    library driver (the path bench.py --gpus N takes on a real node) creates the ncclComm_t itself
+    -- unique id from rank 0, shipped over the process group -- and hands it to
+    spllt_hip_set_communicator; here the one-rank communicator stands in for rank 0 of 2"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(0)
+    os.environ["SPLLT_HIP_COMM_REHEARSAL"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from spllt_amd import api, matgen, multigpu
+        A = matgen.nd_like((12, 11, 10), 2)
+        n, ptr, row, val = api.csc_lower_1based(A)
+        comm, destroy = multigpu.make_rccl_communicator(0, 1)
+        dval = torch.tensor(val, device="cuda")
+        out = {}
+        for drv in ("library", "python"):
+            # width-2 partition, this process is rank 0 of it; library: exchanges inside factor_dev
+            df = multigpu.DistributedFactorization(n, ptr, row, 64, 0, 2, nemin=16, dist_top=True, driver=drv,
+                                                   comm=comm if drv == "library" else None)
+            assert df.driver == drv
+            df.factor(dval)
+            out[drv] = df.f.get_factor()
+            out[drv + "_nx"] = len(df.plan)
+            if drv == "library":
+                assert df.f.pending_exchange() < 0 and "library" in df.phase_ms.get("driver", "")
+                assert "rehearsal" in df.f.last_error()
+            df.close()
+        destroy()
+        a, b = np.nan_to_num(out["library"]), np.nan_to_num(out["python"])
+        same = float(np.abs(a - b).max() / np.abs(b).max()) <= 1e-12     # (fp64 atomics: equal to rounding)
+        ret[0] = (bool(same), out["library_nx"], bool(np.isfinite(out["library"]).all()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_path_library_driver_on_rccl_single_rank():
+    """multigpu.DistributedFactorization(driver="library") -- what bench.py --gpus N uses when the
+    backend is nccl: ncclGetUniqueId on rank 0, the id shipped through the process group,
+    ncclCommInitRank, spllt_hip_set_communicator, and then nothing but factor / wait -- against the
+    Python driver of the same exchanges (torch.distributed on the engine's stream), with the one
+    rank this box has (a one-rank communicator and group standing in for rank 0 of a width-2
+    partition: both drivers leave the other rank's parts out in the same way)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_library_driver_worker, args=(1, 33700 + (os.getpid() % 2000), ret), nprocs=1, join=True)
+    same, nx, finite = ret[0]
+    assert finite and nx >= 3 and same, ret[0]
+
+
 @pytest.mark.gpu
 def test_run_exchange_calls_on_rccl_single_rank():
     """The collectives of multigpu.run_exchange (all-reduce, reduce_scatter_tensor into the
