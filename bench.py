@@ -174,6 +174,41 @@ def run_extra_config(cfg_name, steps=2):
     return out
 
 
+def run_small_config(label, A, nb, nemin, steps=30):
+    """A small problem (BASELINE config 1, the smoke size), where the host's submission is as long as
+    the device's work: wall / host-submit / device time per factorization with eager launches and
+    with the two HIP-graph replays (engine flag bits 17 / 15 / 16) -- what decides the default of
+    row f1 per problem size (reported under detail.small_configs, never as `value`)."""
+    import torch
+    from spllt_amd import api
+    n, ptr, row, val = api.csc_lower_1based(A)
+    dval = torch.tensor(val, device="cuda")
+    out = {"workload": label, "n": n, "nb": nb}
+    for mode, flag in (("default", 0), ("eager", 131072), ("graph_chain", 32768), ("graph_dag", 65536)):
+        f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=False, engine_flags=flag)
+        for _ in range(3):
+            f.factor_dev(dval.data_ptr()).wait()
+        torch.cuda.synchronize()
+        sub, dev = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f.factor_dev(dval.data_ptr()).wait()
+            tm = f.times()
+            sub.append(tm.get("submit_ms", 0.0))
+            dev.append(tm.get("device_ms", 0.0))
+        t = (time.perf_counter() - t0) / steps
+        if mode == "default":
+            si = f.sym_info()
+            b = A @ np.ones(n)
+            x = f.solve(b)
+            out.update(flops_sym=float(si["flops"]), launches=int(len(f.program("launches"))),
+                       bwd_err=float(np.linalg.norm(b - A @ x) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x))))
+        out[mode] = {"wall_ms": round(t * 1e3, 4), "host_submit_ms": round(float(np.mean(sub)), 4),
+                     "device_ms": round(float(np.mean(dev)), 4)}
+        f.close()
+    return out
+
+
 def host_cores(cap=16):
     """cores this process may really use: affinity mask and cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -383,11 +418,18 @@ def main():
             del Am, Bm, Cm
         except Exception as e:   # noqa: BLE001 - a reference point, never a reason to lose the line
             dgemm_ref = {"error": repr(e)[:200]}
-    extra = []
+    extra, small = [], []
     if not args.no_extra_configs and not args.mm and not args.rb and args.scale == 1.0:
         f.close()
         del dval
         torch.cuda.empty_cache()
+        from spllt_amd import matgen as _mg
+        for label, Am_, nb_, nemin_ in (("poisson2d_128 (BASELINE config 1)", _mg.poisson2d(128), 256, 32),
+                                        ("poisson2d_48 (smoke size)", _mg.poisson2d(48), 32, 16)):
+            try:
+                small.append(run_small_config(label, Am_, nb_, nemin_))
+            except Exception as e:   # noqa: BLE001 - a diagnostic, never a reason to lose the line
+                small.append({"workload": label, "error": repr(e)[:200]})
         # (flan_like = BASELINE config 4 on one GPU: 32.7 GB of factor, ~0.8 s per factorization)
         for other in ("poisson3d_128", "serena_like") + (() if os.environ.get("SPLLT_NO_FLAN") else ("flan_like",)):
             if other != args.config:
@@ -408,7 +450,7 @@ def main():
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
                    "launches": nlaunch, "kernel_table": table, "timeline": level_done, "check": check,
                    "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin,
-                   "dgemm_reference": dgemm_ref, "configs": extra},
+                   "dgemm_reference": dgemm_ref, "configs": extra, "small_configs": small},
     }
     print(json.dumps(out))
 

@@ -131,9 +131,10 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * in K slices on a separate stream while the level's panel chains still run),
  * bit 7 = debug: the LDS of every CU is filled with signalling NaNs before every
  * kernel launch (a kernel that reads LDS it has not written then computes NaNs),
- * bit 8 = no CU reservation (default: the streams that carry the trailing updates
- * are masked off the last 32 CUs (latency-bound problems only), which the latency-critical panel-chain kernels then find
- * free).  Bit 9 = no fused panel launches: by default a panel step whose block columns have
+ * bit 8 = no CU reservation (the default since round 4; SPLLT_HIP_RESERVE_CUS=32 masks the
+ * streams that carry the trailing updates off the last 32 CUs, which the latency-critical
+ * panel-chain kernels then find free: 0.6 % on the bench workload, and CU-masked streams are
+ * what rocprofv3 crashes on at exit).  Bit 9 = no fused panel launches: by default a panel step whose block columns have
  * few rows below the panel (at most 64 blocks of 64 rows in the launch) runs as ONE kernel -
  * every workgroup factors the 64 x 64 diagonal block itself, solves its own rows and applies
  * the left-looking update of the next panel's columns to them - instead of a POTRF, a TRSM
@@ -151,9 +152,11 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * (default: by the weight of the top tree, see spllt_hip_set_partition).
  * Bit 15 / bit 16 = HIP-graph replay of the factorization (analyse once, factorize many): one
  * graph per pattern built from the program tables, a chain of kernel nodes in program order / the
- * DAG of the multi-stream program; bit 17 = eager launches (the default: on ROCm 7.2
- * hipGraphLaunch submits nothing before all ~650 nodes are enqueued, 1.7 ms, and a kernel
- * boundary costs the device the same 1.3-1.4 us either way: 25.1 / 24.4 ms against 23.7 eager).
+ * DAG of the multi-stream program; bit 17 = eager launches.  Default: by problem size -- the
+ * chain replay up to 5 GFLOP (0.35 vs 0.48 ms at the smoke size, 0.46 vs 0.69 ms on BASELINE
+ * config 1: there the host's submission is as long as the device's work), the DAG replay up to
+ * 40 GFLOP, eager above (on ROCm 7.2 hipGraphLaunch submits nothing before all nodes are
+ * enqueued: 25.1 / 24.4 ms against 23.7 eager on the 650 launches of the bench workload).
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);

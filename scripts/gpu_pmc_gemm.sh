@@ -7,7 +7,6 @@ OUT=$REPO/gpurun_out/pmc_gemm
 mkdir -p $OUT
 export TMPDIR=/tmp
 # (the library destroys its pooled CU-masked streams at exit only when asked: rocprofv3 crashes on live ones)
-export SPLLT_TEARDOWN=2
 cd /tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/ub -o ub -- $REPO/bin_tmp/ub_cur 8192 8192 > $OUT/ub.log 2>&1
 echo "update_bench rc=$?"

@@ -13,7 +13,6 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $OUT
 export TMPDIR=/tmp
 # (the library destroys its pooled CU-masked streams at exit only when asked: rocprofv3 crashes on live ones)
-export SPLLT_TEARDOWN=2
 cd /tmp
 B="--steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extra-configs $ARGS"
 FAILED=0

@@ -330,7 +330,12 @@ ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
   so.deterministic = opt.deterministic;
   so.fused_panel = opt.fused_panel;
   const bool lb = latency_bound(S, std::min(opt.pw, kPanelMax));
-  if (opt.reserve_cus < 0) opt.reserve_cus = lb ? 32 : 0;
+  // CU reservation (bulk / far streams masked off the last CUs): OFF by default since round 4.  It
+  // bought 24.9 -> 24.4 ms in round 2 and buys 23.35 -> 23.2 ms now (0.6 %, profiles/r04/ab_cu_reserve.txt),
+  // and CU-masked streams are the one object of this library whose destruction can hang
+  // (profiles/r03/hang_evidence.txt) and whose survival makes rocprofv3 crash at exit.  Opt in
+  // with SPLLT_HIP_RESERVE_CUS=32.
+  if (opt.reserve_cus < 0) opt.reserve_cus = 0;
   if (opt.zones < 0) opt.zones = lb ? 1 : 0;
   so.zones = opt.zones != 0;
   // throughput-bound problems use the (LDS-DMA) 128-tile from 1024 tiles on: +0.3-0.9 % on the
@@ -565,11 +570,24 @@ int Engine::upload() {
   // the chip to themselves) is not masked.
   graph_mode_ = opt_.graph;
   if (const char* e = std::getenv("SPLLT_HIP_GRAPH")) graph_mode_ = std::atoi(e);
+  if (graph_mode_ < 0) {
+    // by problem size (profiles/r04/graph_replay_by_size.txt): a small factorization is a few dozen
+    // launches whose submission takes the host as long as the device needs for them -- the replay of
+    // ONE graph wins 20-40 % up to ~3 GFLOP (0.35 vs 0.48 ms at the smoke size, 0.46 vs 0.69 ms on
+    // BASELINE config 1), a few per cent up to ~30 GFLOP, and loses from a few hundred launches on
+    // (hipGraphLaunch submits nothing before all nodes are enqueued: 13.6 vs 12.0 ms at 313 GFLOP)
+    const double fl = (double)S.flops;
+    graph_mode_ = fl <= 5e9 ? 1 : (fl <= 40e9 ? 2 : 0);
+  }
   if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);
   int reserve = opt_.reserve_cus;
   if (const char* e = std::getenv("SPLLT_HIP_RESERVE_CUS")) reserve = std::atoi(e);
+  // a factorization that is replayed as a graph has no streams of its own to mask (the kernel nodes
+  // of a graph go where the runtime puts them): the small, latency-bound problems -- the ones that
+  // used to get CU-masked streams -- no longer create any
+  if (graph_mode_ > 0 && opt_.nranks <= 1 && !opt_.poison_lds && !std::getenv("SPLLT_HIP_RESERVE_CUS")) reserve = 0;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_), "device props");
   const int ncu = prop.multiProcessorCount;
@@ -1239,17 +1257,57 @@ int Engine::wait() {
   return 0;
 }
 
+// device -> pageable host memory through the two pinned staging buffers of stage_val (the mirror
+// image: the DMA of chunk k + 1 flies while the host copies chunk k out; every wait has the
+// deadline).  A plain hipMemcpy into pageable memory moved the 1.5 GB factor of the bench workload
+// at 3.2 GB/s (the runtime stages it itself, one small buffer at a time).
+int Engine::staged_d2h(void* out_host, const void* src_dev, size_t bytes) {
+  if (bytes == 0) return 0;
+  const size_t chunk = kH2dChunk;
+  if (h2d_chunk_ != chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (h2d_busy_[i]) { int rc = wait_event(h2d_ev_[i], "staging"); if (rc) return rc; h2d_busy_[i] = false; }
+      if (h2d_buf_[i]) pin_release(h2d_buf_[i], h2d_chunk_);
+      h2d_buf_[i] = nullptr;
+    }
+    h2d_chunk_ = chunk;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!h2d_buf_[i]) HIPCHK(pin_alloc(&h2d_buf_[i], chunk), "hipHostMalloc(staging)");
+    if (!h2d_ev_[i]) HIPCHK(hipEventCreateWithFlags(&h2d_ev_[i], hipEventDisableTiming), "hipEventCreate");
+    if (h2d_busy_[i]) { int rc = wait_event(h2d_ev_[i], "staging"); if (rc) return rc; h2d_busy_[i] = false; }
+  }
+  char* dst = reinterpret_cast<char*>(out_host);
+  const char* src = reinterpret_cast<const char*>(src_dev);
+  const size_t nchunk = (bytes + chunk - 1) / chunk;
+  auto issue = [&](size_t k) -> int {
+    const size_t off = k * chunk, len = std::min(chunk, bytes - off);
+    HIPCHK(hipMemcpyAsync(h2d_buf_[k & 1], src + off, len, hipMemcpyDeviceToHost, stream_), "L D2H");
+    HIPCHK(hipEventRecord(h2d_ev_[k & 1], stream_), "event");
+    return 0;
+  };
+  int rc = issue(0);
+  if (rc) return rc;
+  for (size_t k = 0; k < nchunk; ++k) {
+    if (k + 1 < nchunk && (rc = issue(k + 1))) return rc;
+    if ((rc = wait_event(h2d_ev_[k & 1], "L D2H staging"))) return rc;
+    const size_t off = k * chunk, len = std::min(chunk, bytes - off);
+    std::memcpy(dst + off, h2d_buf_[k & 1], len);
+  }
+  return 0;
+}
+
 int Engine::download(double* out, int64_t count) {
   if (status_) return status_;
   if (count > S_->arena) count = S_->arena;
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
-  if (loc_off_.empty()) {
-    HIPCHK(hipMemcpy(out, d_L_, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost), "L D2H");
-    return 0;
-  }
+  if (loc_off_.empty()) return staged_d2h(out, d_L_, sizeof(double) * (size_t)count);
   // a rank's arena is packed: back into the global layout (zero where nothing is held here)
   std::vector<double> tmp((size_t)std::max<int64_t>(1, arena_elems_));
-  HIPCHK(hipMemcpy(tmp.data(), d_L_, sizeof(double) * (size_t)arena_elems_, hipMemcpyDeviceToHost), "L D2H");
+  {
+    int rc = staged_d2h(tmp.data(), d_L_, sizeof(double) * (size_t)arena_elems_);
+    if (rc) return rc;
+  }
   std::memset(out, 0, sizeof(double) * (size_t)count);
   for (int b = 0; b < S_->nbcol(); ++b) {
     if (loc_off_[(size_t)b] < 0) continue;

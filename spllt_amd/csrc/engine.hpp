@@ -44,9 +44,9 @@ struct EngineOptions {
                            // problem is latency-bound (schedule.hpp), else 0)
   int zones = -1;          // zone pipeline of the inter-node updates (1 / 0; -1: when latency-bound)
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
-  int graph = 0;           // HIP-graph replay of the factorization (single GPU): 0 eager launches, 1 one
+  int graph = -1;          // HIP-graph replay of the factorization (single GPU): 0 eager launches, 1 one
                            // chain of kernel nodes in program order, 2 the DAG of the multi-stream
-                           // program (env SPLLT_HIP_GRAPH overrides)
+                           // program, -1 by problem size (env SPLLT_HIP_GRAPH overrides)
 };
 
 struct FactorStats {
@@ -177,6 +177,7 @@ class Engine {
   hipEvent_t h2d_ev_[2] = {nullptr, nullptr};
   bool h2d_busy_[2] = {false, false};
   int stage_val(const double* val_host, int64_t nnz);
+  int staged_d2h(void* out_host, const void* src_dev, size_t bytes);
   int wait_event(hipEvent_t ev, const char* what);
   bool poisoned_ = false;   // a wait ran into its deadline: see ~Engine
   bool comm_rehearsal_ = false;   // set_communicator accepted a one-rank stand-in (SPLLT_HIP_COMM_REHEARSAL): results are not the factor

@@ -45,13 +45,19 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("small", [False, True])
 @pytest.mark.parametrize("name,gen,nb,nemin,pw", CASES)
-def test_factor_matches_oracle(name, gen, nb, nemin, pw):
+def test_factor_matches_oracle(name, gen, nb, nemin, pw, small):
+    """small=True: the analyse prunes the tree for four workers (spllt_prune_tree, small(:)) and the
+    ORACLE takes its pruned-subtree path -- one task per small subtree with a private generated
+    element and one extend-add at its root (reference factorization_mod:39-261, kernels_mod:97-821)
+    -- so that this path of the oracle, too, is checked against the GPU engine (which factors the
+    same L through its level-batched launches either way)."""
     A = gen()
-    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw)
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, prune=small, ncpu=4 if small else 1)
     f.factor(val).wait()
     got = f.get_factor()
-    o, rc = oracle_factor(f, val, variant="mkl" if f.n > 4000 else "plain", nthreads=4)
+    o, rc = oracle_factor(f, val, variant="mkl" if f.n > 4000 else "plain", nthreads=4, use_small=small)
     assert rc == 0
     mask = lower_mask(f)
     assert rel_err(got, o.arena(), mask) <= TOL_L
