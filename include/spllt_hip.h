@@ -186,13 +186,17 @@ int spllt_hip_set_chain_block(void *fkeep, int chain_block);
  * src/spllt_factorization_mod.F90:39-191; the last element carries the "not positive definite"
  * indicator); the top tree is then factorized on every rank (replicated).
  * Distributed top tree (engine flag bit 13, or chosen by the engine when the top tree is
- * heavy): kind 1: reduce-scatter(sum) of buffer[0:elems] in nranks chunks, rank r receives chunk
- * r AT buffer[r*chunk:(r+1)*chunk] (the block columns of the top tree that r owns); kind 2:
+ * heavy): kind 1: reduce-scatter(sum) of the REGION buffer[base:elems], base = elems - nranks *
+ * chunk, in nranks chunks, rank r receives chunk r AT buffer[base + r*chunk : base + (r+1)*chunk]
+ * (the block columns of ONE LEVEL of the top tree that r owns: there is one such exchange per
+ * level of the top tree, lowest level first, each with a region of its own, so that the lowest
+ * level is factorized while the chunks of the levels above travel; spllt_hip_exchange_stream);
+ * kind 2:
  * for every root with items, broadcast of that root's segment of the buffer (its items are
  * contiguous) - the block columns of a finished step go from their owners to all ranks, which
  * then update the destination block columns they own; kind 3: all-reduce(sum) of buffer[0:1],
  * the "not positive definite" indicator, at the very end.
- * exchange_elems: doubles the exchange buffer must hold (the largest exchange). */
+ * exchange_elems: doubles the exchange buffer must hold (all reduce regions + the largest broadcast). */
 int spllt_hip_set_partition(void *fkeep, int rank, int nranks, int64_t *exchange_elems);
 /* The collectives INSIDE the library: hand over the caller's RCCL communicator (ncclComm_t, one
  * rank per GPU, its rank / size = the partition's) after spllt_hip_set_partition.  From then on
@@ -230,6 +234,12 @@ int spllt_hip_set_exchange_buffer(void *fkeep, void *dev_ptr);
  * the phases of a partitioned factorization.  Creates the device engine if necessary;
  * NULL without a HIP device. */
 void *spllt_hip_engine_stream(void *fkeep);
+/* The stream the PENDING exchange (spllt_hip_pending_exchange) is packed and unpacked on: the
+ * stream of spllt_hip_engine_stream, except for the per-level reduce-scatters of a distributed
+ * top tree, which the multi-stream program issues on a side stream so that the chunks of the
+ * upper top-tree levels travel while the lowest one is already being factorized (SURVEY 8(e):
+ * "pipeline per ancestor node").  The caller's collective for that exchange goes on THIS stream. */
+void *spllt_hip_exchange_stream(void *fkeep);
 int spllt_hip_continue(void *fkeep);
 /* "arena_elems" (int64 x 2: doubles of the factor arena held on this rank's device once its engine
  * exists - a rank stores only its own branches and the top tree, packed -, doubles of the whole arena),

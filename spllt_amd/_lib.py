@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "spllt_hip_pending_exchange",
     "spllt_hip_partition_get", "spllt_hip_solve_dev", "spllt_hip_set_chain_block", "spllt_hip_engine_stream", "spllt_hip_analyse_symbolic", "spllt_hip_profile_in_program", "spllt_hip_timeline",
     "spllt_hip_read_rb", "spllt_hip_read_mm", "spllt_hip_free_matrix", "spllt_hip_set_communicator",
-    "spllt_hip_last_flag", "spllt_hip_debug",
+    "spllt_hip_last_flag", "spllt_hip_debug", "spllt_hip_exchange_stream",
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def load():
     lib.spllt_hip_set_engine.restype = C.c_int
     lib.spllt_hip_engine_stream.argtypes = [vp]
     lib.spllt_hip_engine_stream.restype = vp
+    lib.spllt_hip_exchange_stream.argtypes = [vp]
+    lib.spllt_hip_exchange_stream.restype = vp
     lib.spllt_hip_set_chain_block.argtypes = [vp, C.c_int]
     lib.spllt_hip_set_chain_block.restype = C.c_int
     lib.spllt_hip_wait.argtypes = [vp]

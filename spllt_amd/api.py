@@ -286,6 +286,10 @@ class Factorization:
             raise SplltError("spllt_hip_engine_stream", -30, self.last_error())
         return int(p)
 
+    def exchange_stream(self):
+        """hipStream_t (integer) of the pending exchange: its collective belongs on this stream"""
+        return int(self.lib.spllt_hip_exchange_stream(self.fkeep) or 0)
+
     def continue_after_exchange(self):
         rc = self.lib.spllt_hip_continue(self.fkeep)
         if rc < 0:

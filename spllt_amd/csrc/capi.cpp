@@ -662,6 +662,12 @@ void* spllt_hip_engine_stream(void* fkeep) {
   return (void*)f->eng->stream();
 }
 
+void* spllt_hip_exchange_stream(void* fkeep) {
+  Fkeep* f = static_cast<Fkeep*>(fkeep);
+  if (!f || !f->S || !f->eng) return spllt_hip_engine_stream(fkeep);
+  return (void*)f->eng->pending_exchange_stream();
+}
+
 int spllt_hip_set_communicator(void* fkeep, void* nccl_comm) {
   Fkeep* f = static_cast<Fkeep*>(fkeep);
   if (!f || !f->S) return SPLLT_ERROR_PARAMETER;

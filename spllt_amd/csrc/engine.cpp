@@ -608,6 +608,7 @@ int Engine::upload() {
   HIPCHK(hipEventCreate(&ev0_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev1_), "hipEventCreate");
   HIPCHK(hipEventCreate(&ev_h2d_), "hipEventCreate");
+  HIPCHK(hipEventCreateWithFlags(&ev_init_, hipEventDisableTiming), "hipEventCreate");
   // (+ 32 doubles: the update kernel loads whole 16-column chunks, the last one of a ragged K
   // window reaches past the block column's end)
   HIPCHK(dalloc((void**)&d_L_, sizeof(double) * (size_t)(std::max<int64_t>(1, arena_elems_) + 32)), "hipMalloc(L arena)");
@@ -755,6 +756,7 @@ Engine::~Engine() {
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   if (ev_h2d_) hipEventDestroy(ev_h2d_);
+  if (ev_init_) hipEventDestroy(ev_init_);
   if (streams_[ST_CHAIN]) return_streams(streams_[ST_CHAIN]);   // drained above; back into the pool
   crumb("engine: destroyed");
 }
@@ -954,6 +956,15 @@ int Engine::enqueue_program() {
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
   launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
+  if (!prog_.exchanges.empty()) {
+    // A partitioned program may have an exchange as its FIRST launch on a stream other than this one
+    // (a rank that owns no subtree: its phase 1 is empty, and the per-level reduce-scatters of a
+    // distributed top tree run on the side stream): nothing would order its pack behind the clearing
+    // of the arena and the scatter of the values above.  Every other stream starts behind them.
+    HIPCHK(hipEventRecord(ev_init_, stream_), "event");
+    for (int i = 0; i < ST_COUNT; ++i)
+      if (streams_[i] && streams_[i] != stream_) HIPCHK(hipStreamWaitEvent(streams_[i], ev_init_, 0), "init wait");
+  }
   stats_.launches = (int)prog_.launches.size() + 1;
   if (!prog_.exchanges.empty() && !xbuf_) return fail(-10, "exchange buffer not set", hipSuccess);
   return run_from(0);
@@ -980,17 +991,25 @@ int Engine::run_from(size_t first) {
 // The part of an exchange in front of the collective: its dependencies, then what this rank
 // contributes goes into the exchange buffer (all on the chain stream, where the caller then
 // enqueues the collective).
+// the stream an exchange runs on: pack, collective and unpack (the chain stream, or -- the per-level
+// reduce-scatters of a distributed top tree in the multi-stream program -- the side stream, so that
+// the chunks of the upper levels travel while the lowest top level is already being factorized)
+hipStream_t Engine::exchange_stream(const Launch& X) const {
+  return (X.stream >= 0 && X.stream < ST_COUNT && streams_[X.stream]) ? streams_[X.stream] : stream_;
+}
+
 int Engine::pre_exchange(const Launch& X) {
   const Exchange& E = prog_.exchanges[(size_t)X.first];
+  hipStream_t xs = exchange_stream(X);
   for (int w : X.wait)
-    if (w >= 0) HIPCHK(hipStreamWaitEvent(stream_, dag_events_[w], 0), "exchange wait");
+    if (w >= 0) HIPCHK(hipStreamWaitEvent(xs, dag_events_[w], 0), "exchange wait");
   for (int i = E.first_item; i < E.first_item + E.nitems; ++i) {
     const ExchangeItem& it = prog_.xitems[(size_t)i];
     if (E.kind == X_BCAST && it.root != opt_.rank) continue;   // the owner sends
     HIPCHK(hipMemcpyAsync(xbuf_ + it.xoff, (it.space ? d_dinv_ : d_L_) + it.off, sizeof(double) * (size_t)it.count,
-                          hipMemcpyDeviceToDevice, stream_), "pack exchange");
+                          hipMemcpyDeviceToDevice, xs), "pack exchange");
   }
-  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_pack(stream_, d_flag_, xbuf_ + (E.elems - 1));
+  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_pack(xs, d_flag_, xbuf_ + (E.elems - 1));
   HIPCHK(hipGetLastError(), "kernel launch");
   return 0;
 }
@@ -998,15 +1017,16 @@ int Engine::pre_exchange(const Launch& X) {
 // ... and behind it: what this rank needs comes out of the buffer, the exchange's event fires.
 int Engine::post_exchange(const Launch& X) {
   const Exchange& E = prog_.exchanges[(size_t)X.first];
+  hipStream_t xs = exchange_stream(X);
   for (int i = E.first_item; i < E.first_item + E.nitems; ++i) {
     const ExchangeItem& it = prog_.xitems[(size_t)i];
     if (E.kind == X_BCAST && it.root == opt_.rank) continue;          // already here
     if (E.kind == X_REDUCE_OWNER && it.root != opt_.rank) continue;   // somebody else's sum
     HIPCHK(hipMemcpyAsync((it.space ? d_dinv_ : d_L_) + it.off, xbuf_ + it.xoff, sizeof(double) * (size_t)it.count,
-                          hipMemcpyDeviceToDevice, stream_), "unpack exchange");
+                          hipMemcpyDeviceToDevice, xs), "unpack exchange");
   }
-  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_unpack(stream_, xbuf_ + (E.elems - 1), d_flag_);
-  if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], stream_), "exchange record");
+  if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) launch_flag_unpack(xs, xbuf_ + (E.elems - 1), d_flag_);
+  if (X.record >= 0) HIPCHK(hipEventRecord(dag_events_[X.record], xs), "exchange record");
   return 0;
 }
 
@@ -1120,14 +1140,16 @@ int Engine::set_communicator(void* nccl_comm) {
 
 // the collective of one exchange on the exchange buffer, in place, enqueued on the engine's stream
 // (between pre_exchange's pack and post_exchange's unpack)
-int Engine::collective(const Exchange& E) {
+int Engine::collective(const Exchange& E, hipStream_t xs) {
   Rccl& R = rccl();
   if (E.kind == X_REDUCE_ALL || E.kind == X_FLAG) {
-    NCCLCHK(R.all_reduce(xbuf_, xbuf_, (size_t)E.elems, kNcclDouble, kNcclSum, comm_, stream_), "ncclAllReduce");
+    NCCLCHK(R.all_reduce(xbuf_, xbuf_, (size_t)E.elems, kNcclDouble, kNcclSum, comm_, xs), "ncclAllReduce");
   } else if (E.kind == X_REDUCE_OWNER) {
-    // in place: rank r receives into its own chunk of the send buffer
-    NCCLCHK(R.reduce_scatter(xbuf_, xbuf_ + (int64_t)comm_rank_ * E.chunk, (size_t)E.chunk, kNcclDouble, kNcclSum,
-                             comm_, stream_), "ncclReduceScatter");
+    // in place: rank r receives into its own chunk of the region (the region of this level's
+    // exchange ends at E.elems: schedule.cpp)
+    double* region = xbuf_ + (E.elems - (int64_t)opt_.nranks * E.chunk);
+    NCCLCHK(R.reduce_scatter(region, region + (int64_t)comm_rank_ * E.chunk, (size_t)E.chunk, kNcclDouble, kNcclSum,
+                             comm_, xs), "ncclReduceScatter");
   } else if (E.kind == X_BCAST) {
     // one broadcast per root (the items of a root are contiguous in the buffer), as one group
     // (a failed broadcast does not leave the group open: ncclGroupEnd is always reached -- the
@@ -1143,7 +1165,7 @@ int Engine::collective(const Exchange& E) {
              prog_.xitems[(size_t)j].xoff == a.xoff + cnt; ++j)
         cnt += prog_.xitems[(size_t)j].count;
       const int r = R.broadcast(xbuf_ + a.xoff, xbuf_ + a.xoff, (size_t)cnt, kNcclDouble, a.root % comm_size_, comm_,
-                                stream_);
+                                xs);
       if (r != 0 && first_err == 0) first_err = r;
       i = j;
     }
@@ -1159,7 +1181,7 @@ int Engine::run_exchanges() {
   while (awaiting_exchange_) {
     if (!comm_) return 0;                     // the caller drives the exchanges (spllt_hip_continue)
     const Exchange& E = prog_.exchanges[(size_t)prog_.launches[cur_x_].first];
-    int rc = collective(E);
+    int rc = collective(E, exchange_stream(prog_.launches[cur_x_]));
     if (rc) return rc;
     rc = continue_after_exchange();
     if (rc) return rc;

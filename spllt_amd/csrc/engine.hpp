@@ -122,6 +122,8 @@ class Engine {
   int prepare_solve();
   double* device_L() { return d_L_; }
   hipStream_t stream() { return stream_; }
+  // the stream the pending exchange is packed / unpacked on (its collective belongs there); the chain stream when none is pending
+  hipStream_t pending_exchange_stream() const { return awaiting_exchange_ ? exchange_stream(prog_.launches[cur_x_]) : stream_; }
   const Program& program() const { return prog_; }
   const Symbolic& symbolic() const { return *S_; }
   const FactorStats& stats() const { return stats_; }
@@ -163,7 +165,7 @@ class Engine {
   // reserve_cus CUs instead
   int bulk_pad128_ = 0, bulk_pad64_ = 0;
   std::vector<hipEvent_t> dag_events_;  // dependency events of the program
-  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_h2d_ = nullptr, ev_init_ = nullptr;
   // device buffers of this engine (pointer, bytes): taken from / returned to the process-wide cache
   std::vector<std::pair<void*, size_t>> owned_;
   hipError_t dalloc(void** p, size_t bytes);
@@ -192,7 +194,8 @@ class Engine {
   double* xbuf_ = nullptr;          // caller-owned device buffer of xchg_elems_ doubles
   void* comm_ = nullptr;            // ncclComm_t (set_communicator)
   int comm_rank_ = 0, comm_size_ = 1;
-  int collective(const Exchange& E);
+  int collective(const Exchange& E, hipStream_t xs);
+  hipStream_t exchange_stream(const Launch& X) const;
   double* d_owned_ = nullptr;       // per pivot position: 1.0 where this rank contributes to a distributed vector
   std::vector<int> owner_;          // per node: owning rank or -1 (top tree)
   std::vector<int> top_bcols_;      // block columns of the top tree, in order

@@ -249,6 +249,7 @@ struct Builder {
   // dist2 (phase 2 of a program with a distributed top tree): only the destination block columns
   // this rank owns
   bool dist2 = false;
+  int64_t xbcast_base = 0;   // offset of the broadcast area in the exchange buffer (behind the reduce regions)
   bool mine(int b) const { return !dist2 || opt.top_owner[b] == opt.rank; }
 
   void between_templates(int s, std::vector<UpdUnit>& out) {
@@ -525,14 +526,35 @@ struct Builder {
       if (take) by_level[S.level[s]].push_back(s);
     }
     dist2 = partitioned && ph == 1 && opt.top_owner != nullptr;
+    // event of the extend-add that delivers the block columns of a top-tree level (distributed top
+    // tree, multi-stream program: one reduce-scatter per level, see below); -1: nothing to wait for
+    std::vector<int> xlev_event((size_t)maxlevel + 2, -1);
+    int xlev_last = -1;
+    bool xpipe = false;
     if (partitioned && ph == 1) {
       // extend-add of the top-tree block columns across the ranks
-      Exchange E{};
-      E.first_item = (int)P.xitems.size();
       std::vector<int> top;
       for (int b = 0; b < S.nbcol(); ++b)
         if (opt.node_owner[S.bcols[b].node] < 0) top.push_back(b);
+      auto push_exchange = [&](const Exchange& E, int stream, int wait_ev) {
+        Launch X;
+        X.kind = L_EXCHANGE;
+        X.level = -1;
+        X.first = (int64_t)P.exchanges.size();
+        X.count = 0;
+        P.exchanges.push_back(E);
+        X.tile = 0;
+        X.flops = 0;
+        X.stream = stream;
+        X.add_wait(wait_ev);
+        const int ev = P.nevents++;
+        X.record = ev;
+        P.launches.push_back(X);
+        return ev;
+      };
       if (!dist2) {
+        Exchange E{};
+        E.first_item = (int)P.xitems.size();
         E.kind = X_REDUCE_ALL;
         int64_t o = 0;
         for (int b : top) {
@@ -542,41 +564,69 @@ struct Builder {
         }
         E.elems = o + 1;   // + the "not positive definite" indicator
         E.chunk = 0;
+        E.nitems = (int)P.xitems.size() - E.first_item;
+        P.xbuf_elems = std::max(P.xbuf_elems, E.elems);
+        const int ev = push_exchange(E, ST_CHAIN, ev_level);   // (waits for everything of phase 1, all streams)
+        ev_level = ev;
+        zone_events.clear();
+        zone_events.push_back({0, ev});   // phase 2 starts behind the exchange
       } else {
-        E.kind = X_REDUCE_OWNER;
-        std::vector<int64_t> fill((size_t)opt.nranks, 0);
-        for (int b : top) fill[(size_t)opt.top_owner[b]] += (int64_t)S.bcols[b].nrow * S.bcols[b].width;
-        int64_t chunk = 1;
-        for (int64_t v : fill) chunk = std::max(chunk, v);
-        std::fill(fill.begin(), fill.end(), 0);
-        for (int r = 0; r < opt.nranks; ++r)
-          for (int b : top) {
-            if (opt.top_owner[b] != r) continue;
-            const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
-            P.xitems.push_back(ExchangeItem{b, r, (int64_t)r * chunk + fill[(size_t)r], cnt, S.bcols[b].off, 0});
-            fill[(size_t)r] += cnt;
-          }
-        E.chunk = chunk;
-        E.elems = chunk * opt.nranks;
+        // Distributed top tree: reduce-scatter to the owners -- PIPELINED BY LEVEL of the top tree
+        // ("pipeline per ancestor node so the reduce overlaps"; the reference's walk is
+        // per destination tile, src/spllt_factorization_mod.F90:39-191).  One exchange per level,
+        // lowest first, each with its own region of the buffer (rank r's chunk of level l at
+        // base_l + r chunk_l; Exchange::elems = the END of the region, i.e. base_l = elems -
+        // nranks chunk_l), issued back to back on the SIDE stream of the multi-stream program: a
+        // step of top level l waits for chunk l only, so the lowest top level's panel chains run
+        // while the (larger) chunks of the levels above are still on the wire.  What lands in a
+        // level (the inter-node updates of the levels below it) waits for that level's chunk too:
+        // the unpack overwrites.  The single-stream program issues them in a row on its one stream.
+        std::vector<int> tlev;
+        for (int b : top) tlev.push_back(S.level[S.bcols[b].node]);
+        std::sort(tlev.begin(), tlev.end());
+        tlev.erase(std::unique(tlev.begin(), tlev.end()), tlev.end());
+        xpipe = la;
+        int64_t base = 0;
+        int wait_ev = ev_level;
+        for (int tl : tlev) {
+          Exchange E{};
+          E.first_item = (int)P.xitems.size();
+          E.kind = X_REDUCE_OWNER;
+          std::vector<int64_t> fill((size_t)opt.nranks, 0);
+          for (int b : top)
+            if (S.level[S.bcols[b].node] == tl) fill[(size_t)opt.top_owner[b]] += (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+          int64_t chunk = 1;
+          for (int64_t v : fill) chunk = std::max(chunk, v);
+          std::fill(fill.begin(), fill.end(), 0);
+          for (int r = 0; r < opt.nranks; ++r)
+            for (int b : top) {
+              if (S.level[S.bcols[b].node] != tl || opt.top_owner[b] != r) continue;
+              const int64_t cnt = (int64_t)S.bcols[b].nrow * S.bcols[b].width;
+              P.xitems.push_back(ExchangeItem{b, r, base + (int64_t)r * chunk + fill[(size_t)r], cnt, S.bcols[b].off, 0});
+              fill[(size_t)r] += cnt;
+            }
+          E.chunk = chunk;
+          base += chunk * opt.nranks;
+          E.elems = base;
+          E.nitems = (int)P.xitems.size() - E.first_item;
+          const int ev = push_exchange(E, xpipe ? ST_SIDE : ST_CHAIN, wait_ev);
+          wait_ev = -1;                  // (the following ones are behind it in their stream)
+          xlev_event[(size_t)tl] = ev;
+          xlev_last = ev;
+        }
+        P.xbuf_elems = std::max(P.xbuf_elems, base);
+        xbcast_base = base;              // the broadcasts of phase 2 use the buffer behind the reduce regions
+        if (!xpipe) {
+          ev_level = xlev_last;
+          zone_events.clear();
+          zone_events.push_back({0, xlev_last});
+        } else {
+          // every level of phase 2 waits for its own chunk (below); nothing of phase 1 is left to wait for
+          ev_level = xlev_event[(size_t)tlev.front()];
+          zone_events.clear();
+          zone_events.push_back({0, ev_level});
+        }
       }
-      E.nitems = (int)P.xitems.size() - E.first_item;
-      P.xbuf_elems = std::max(P.xbuf_elems, E.elems);
-      Launch X;
-      X.kind = L_EXCHANGE;
-      X.level = -1;
-      X.first = (int64_t)P.exchanges.size();
-      X.count = 0;
-      P.exchanges.push_back(E);
-      X.tile = 0;
-      X.flops = 0;
-      X.stream = ST_CHAIN;
-      X.add_wait(ev_level);  // everything of phase 1, all streams
-      int ev = P.nevents++;
-      X.record = ev;
-      ev_level = ev;
-      zone_events.clear();
-      zone_events.push_back({0, ev});   // phase 2 starts behind the exchange
-      P.launches.push_back(X);
     }
     for (int lev = 0; lev <= maxlevel; ++lev) {
       const auto& nodes = by_level[lev];
@@ -606,6 +656,15 @@ struct Builder {
       std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
       std::vector<int> emitted(nodes.size(), 0);
       for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
+      if (xpipe && xlev_event[(size_t)lev] >= 0) {
+        // pipelined extend-add: the block columns of this top-tree level are here when their own
+        // reduce-scatter is (every launch of the level is behind this marker: in the chain stream's
+        // order, or through the chain's events)
+        std::vector<UpdUnit> none;
+        Edge e = edge(ST_CHAIN);
+        e.wait0 = xlev_event[(size_t)lev];
+        emit_gemm(lev, none, 0.0, true, e);
+      }
       for (int c = 0; c < maxnc; ++c) {
         int maxw = 0;
         for (int s : nodes) {
@@ -833,7 +892,7 @@ struct Builder {
             Exchange E{};
             E.kind = X_BCAST;
             E.first_item = (int)P.xitems.size();
-            int64_t o = 0;
+            int64_t o = xbcast_base;
             for (int r = 0; r < opt.nranks; ++r)
               for (int s : nodes) {
                 const int nc = S.node_bcol0[s + 1] - S.node_bcol0[s];
@@ -969,7 +1028,10 @@ struct Builder {
             // (4b) early inter-node slices: block columns 0..c are final, so the part
             // of update_between that reads them can run beside the remaining panel
             // chains of the level (far stream) instead of after the last one
-            if (la && opt.slice_between && !det && c + 1 < maxnc) {
+            // (pipelined extend-add: no early slices -- they would add into levels whose chunk may
+            // still be on the wire, and a far stream that waits for the last chunk holds up the
+            // zones of the next level behind it)
+            if (la && opt.slice_between && !det && !xpipe && c + 1 < maxnc) {
               std::vector<UpdUnit> sl;
               double fs_ = collect_between(nodes, tmpl, emitted, c + 1, false, sl);
               if (!sl.empty()) {
@@ -1000,6 +1062,7 @@ struct Builder {
         if (la) {
           e.wait0 = evD_last;
           e.wait1 = ev_level;
+          if (xpipe) e.wait2 = xlev_last;     // (the buffered blocks land in every level above)
         }
         emit_buffered(lev, rest, fl, e);
         if (la) {
@@ -1016,7 +1079,9 @@ struct Builder {
         const bool use_zones = !det && (zones_env >= 0 ? zones_env != 0 : opt.zones);
         auto zone_of = [&](const UpdUnit& u) {
           const int a = S.bcols[u.dinv_ld].node;
-          if (!use_zones) return 0;   // one zone: every step of the next level waits for all of it
+          // one zone: every step of the next level waits for all of it (pipelined extend-add: what
+          // goes beyond the next level is still a group of its own -- it waits for the last chunk)
+          if (!use_zones) return (xpipe && S.level[a] != lev + 1) ? INT_MAX : 0;
           if (S.level[a] != lev + 1) return INT_MAX;
           return u.dinv_ld - S.node_bcol0[a];
         };
@@ -1035,10 +1100,25 @@ struct Builder {
           e.record = ev_level;
           emit_gemm(lev, none, 0.0, true, e);
           zone_events.push_back({-1, ev_level});
+          if (xpipe && lev + 1 <= maxlevel && xlev_event[(size_t)lev + 1] >= 0) {
+            // the zones of the next level add into block columns that its own chunk overwrites
+            Edge e2 = edge(ST_FAR);
+            e2.wait0 = xlev_event[(size_t)lev + 1];
+            emit_gemm(lev, none, 0.0, true, e2);
+          }
         }
         size_t i = 0;
+        bool rest_waited = false;
         while (i < rest.size()) {
           const int z = zone_of(rest[i]);
+          if (xpipe && z == INT_MAX && !rest_waited) {
+            // what goes beyond the next level may land anywhere above: behind the last chunk
+            std::vector<UpdUnit> none;
+            Edge e2 = edge(ST_FAR);
+            e2.wait0 = xlev_last;
+            emit_gemm(lev, none, 0.0, true, e2);
+            rest_waited = true;
+          }
           std::vector<UpdUnit> grp;
           double fz = 0;
           for (; i < rest.size() && zone_of(rest[i]) == z; ++i) {

@@ -41,7 +41,9 @@ X_REDUCE_ALL, X_REDUCE_OWNER, X_BCAST, X_FLAG = 0, 1, 2, 3
 
 def exchange_plan(f):
     """Per exchange of f's program (include/spllt_hip.h, spllt_hip_set_partition):
-    (kind, elems, chunk, segments) with segments = [(root, offset, length)] of an X_BCAST."""
+    (kind, elems, chunk, segments) with segments = [(root, offset, length)] of an X_BCAST.
+    An X_REDUCE_OWNER (one per level of a distributed top tree) covers the REGION
+    [elems - world * chunk, elems) of the buffer."""
     plan = []
     items = f.program("xitems")
     for kind, first, n, elems, chunk in f.program("exchanges").tolist():
@@ -67,12 +69,13 @@ def run_exchange(xbuf, step, rank, world, group=None, scratch=None, force=False)
     if kind in (X_REDUCE_ALL, X_FLAG):
         dist.all_reduce(xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
     elif kind == X_REDUCE_OWNER:
+        base = elems - world * chunk           # the region of this level's exchange
         if dist.get_backend(group) == "nccl":
             out = scratch[:chunk] if scratch is not None else xbuf.new_empty(chunk)
-            dist.reduce_scatter_tensor(out, xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
-            xbuf[rank * chunk:(rank + 1) * chunk].copy_(out)
+            dist.reduce_scatter_tensor(out, xbuf[base:elems], op=dist.ReduceOp.SUM, group=group)
+            xbuf[base + rank * chunk:base + (rank + 1) * chunk].copy_(out)
         else:
-            dist.all_reduce(xbuf[:elems], op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(xbuf[base:elems], op=dist.ReduceOp.SUM, group=group)
     elif kind == X_BCAST:
         for root, off, cnt in segs:
             src = dist.get_global_rank(group, root) if group is not None else root
@@ -174,12 +177,15 @@ class DistributedFactorization:
         engine's pack and unpack"""
         import torch
         step = self.plan[k]
+        # the stream THIS exchange is packed / unpacked on (the per-level reduce-scatters of a
+        # distributed top tree run on a side stream of the engine)
+        ext = torch.cuda.ExternalStream(self.f.exchange_stream())
         if self.stream_ordered:
-            with torch.cuda.stream(self.ext):
+            with torch.cuda.stream(ext):
                 run_exchange(self.xbuf, step, self.rank, self.world, self.group, self.scratch)   # RCCL: enqueue only
         else:
             # gloo (CPU tests / one-GPU rehearsal) stages through the host: plain syncs
-            self.ext.synchronize()
+            ext.synchronize()
             run_exchange(self.xbuf, step, self.rank, self.world, self.group, self.scratch)
             torch.cuda.synchronize()
 

@@ -301,8 +301,9 @@ class LockstepExchange:
             res = np.full_like(bufs[r], np.nan)
             if kind in (0, 3):
                 res[:elems] = np.sum([b[:elems] for b in bufs], axis=0)
-            elif kind == 1:
-                res[r * chunk:(r + 1) * chunk] = np.sum([b[r * chunk:(r + 1) * chunk] for b in bufs], axis=0)
+            elif kind == 1:      # the region of this level's reduce-scatter ends at elems
+                lo = elems - self.world * chunk + r * chunk
+                res[lo:lo + chunk] = np.sum([b[lo:lo + chunk] for b in bufs], axis=0)
             else:
                 for root, off, cnt in segs:
                     res[off:off + cnt] = bufs[root][off:off + cnt]

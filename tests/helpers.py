@@ -102,8 +102,9 @@ def drive_exchanges(fs, bufs, on_exchange=None):
             b.fill_(float("nan"))
             if kind in (0, 3):
                 b[:elems] = torch.stack([s[:elems] for s in src]).sum(dim=0)
-            elif kind == 1:
-                b[r * chunk:(r + 1) * chunk] = torch.stack([s[r * chunk:(r + 1) * chunk] for s in src]).sum(dim=0)
+            elif kind == 1:      # the region of this level's reduce-scatter ends at elems
+                lo = elems - world * chunk + r * chunk
+                b[lo:lo + chunk] = torch.stack([s[lo:lo + chunk] for s in src]).sum(dim=0)
             else:
                 for root, off, cnt in segs:
                     b[off:off + cnt] = src[root][off:off + cnt]

@@ -76,8 +76,11 @@ def test_partitioned_program_over_gloo(case, world, top):
         if top == "replicated":
             assert nx == 1 and kinds == [0]          # exactly one exchange point: the all-reduce
         else:
-            # reduce-scatter to the owners, a broadcast per finished block-column step, the indicator
-            assert nx == len(kinds) >= 3 and kinds[0] == 1 and kinds[-1] == 3 and set(kinds[1:-1]) == {2}
+            # reduce-scatter to the owners (one per level of the top tree), a broadcast per finished
+            # block-column step, the indicator
+            nred = kinds.count(1)
+            assert nx == len(kinds) >= 3 and nred >= 1 and kinds[:nred] == [1] * nred
+            assert kinds[-1] == 3 and set(kinds[nred:-1]) == {2}
         assert set(owners) == set(range(world)) | {-1}
 
 
@@ -403,7 +406,17 @@ def test_top_tree_block_column_owners(world):
     if len(top) >= world:
         assert set(towner[top].tolist()) == set(range(world))
     ex0, it0 = f.program("exchanges"), f.program("xitems")
-    assert ex0[0, 0] == 1 and ex0[-1, 0] == 3 and np.all(ex0[1:-1, 0] == 2)
+    # the extend-add first -- one reduce-scatter per level of the top tree, lowest level first, each
+    # with a region of its own in the buffer --, then the broadcasts of the steps, the flag last
+    nred = int((ex0[:, 0] == 1).sum())
+    assert nred == len(set(level[bc_node[top]].tolist())) >= 1
+    assert np.all(ex0[:nred, 0] == 1) and ex0[-1, 0] == 3 and np.all(ex0[nred:-1, 0] == 2)
+    red_levels = [sorted(set(level[bc_node[it0[first:first + n, 0]]].tolist())) for kind, first, n, *_ in ex0[:nred].tolist()]
+    assert all(len(lv) == 1 for lv in red_levels) and [lv[0] for lv in red_levels] == sorted(lv[0] for lv in red_levels)
+    ends = ex0[:nred, 3].tolist()
+    assert ends == sorted(ends) and all(e - world * c == (ends[i - 1] if i else 0) for i, (e, c) in enumerate(zip(ends, ex0[:nred, 4].tolist())))
+    bcast_lo = min([int(it0[first:first + n, 2].min()) for kind, first, n, *_ in ex0.tolist() if kind == 2 and n] + [ends[-1]])
+    assert bcast_lo >= ends[-1], "the broadcasts use the buffer behind the reduce regions"
     for g in fs[1:]:
         assert np.array_equal(g.program("exchanges"), ex0) and np.array_equal(g.program("xitems"), it0)
         assert np.array_equal(g.partition("top_bcol_owner"), towner)
@@ -413,9 +426,9 @@ def test_top_tree_block_column_owners(world):
         if kind == 2:
             assert all(int(towner[b]) == root for b, root in items[:, :2].tolist())
         if kind == 1:
-            assert elems == chunk * world
+            base = elems - chunk * world
             for b, root, xo, cnt, off, space in items.tolist():
-                assert root * chunk <= xo and xo + cnt <= (root + 1) * chunk and space == 0
+                assert base + root * chunk <= xo and xo + cnt <= base + (root + 1) * chunk and space == 0
 
 
 def test_top_tree_is_distributed_only_when_it_pays():
@@ -436,3 +449,68 @@ def test_top_tree_is_distributed_only_when_it_pays():
     h, _ = make_case(big, nb=384, nemin=32, prune=True, ncpu=4)
     h.set_partition(0, 4)
     assert len(h.partition("top_bcol_owner")) > 0              # distributed by choice
+
+
+def test_extend_add_is_pipelined_by_top_tree_level():
+    """Distributed top tree, multi-stream program: the reduce-scatter of the extend-add is one
+    exchange per LEVEL of the top tree, lowest first, on the side stream ("pipeline per
+    ancestor node so the reduce overlaps"; the reference's walk is per destination tile,
+    src/spllt_factorization_mod.F90:39-191) -- the panel chains of top level l wait for chunk l
+    only, the updates that land in a level wait for that level's chunk (the unpack overwrites),
+    nothing waits for more than it needs.  Checked: the structure, the stream DAG of every rank
+    (every conflict ordered), the numbers in lockstep -- and that the order really hangs on the
+    per-level waits (mutation: a rank whose program lost the wait in front of a top level is caught
+    by the DAG check)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_schedule as ts
+    from emulate import emulate_ranks
+    from helpers import dense_arena, lower_mask, make_case
+    from spllt_amd import matgen
+    A = matgen.nd_like((12, 11, 10), 2)
+    world = 4
+    fs = []
+    for r in range(world):
+        f, val = make_case(A, nb=32, nemin=8, prune=True, ncpu=world, panel_width=16, engine_flags=8192)
+        f.set_partition(r, world)
+        f.rank = r
+        fs.append(f)
+    f = fs[0]
+    L, ex = f.program("launches"), f.program("exchanges")
+    xl = L[L[:, 0] == 2]
+    nred = int((ex[:, 0] == 1).sum())
+    assert nred >= 2, "the case is meant to have a top tree of several levels"
+    assert (xl[:nred, 6] == 3).all(), "the per-level reduce-scatters run on the side stream"
+    assert (xl[nred:, 6] == 0).all(), "broadcasts and the flag stay on the chain stream"
+    assert xl[0, 8] >= 0 and (xl[1:nred, 8:12] == -1).all(), "the first waits for phase 1, the others follow in their stream"
+    recs = xl[:nred, 7].tolist()
+    # every chunk's event is waited for by a marker of the chain stream (the level's own start) ...
+    waited = {int(w) for row in L[(L[:, 0] == 1) & (L[:, 3] == 0)] for w in row[8:12] if w >= 0}
+    assert set(recs) <= waited | {int(w) for row in L for w in row[8:12] if w >= 0}
+    for g in fs:
+        assert not ts.dag_violations(g)[0]
+    arenas = emulate_ranks(fs, val)
+    ref, mask = dense_arena(f, A), lower_mask(f)
+    owner, bc_node = f.partition("owner"), f.sym("bcol_node")
+    off, w, nr = f.sym("bcol_off"), f.sym("bcol_width"), f.sym("bcol_nrow")
+    for r, g in enumerate(fs):
+        mine = np.zeros_like(mask)
+        for b in range(len(off)):
+            if owner[bc_node[b]] in (r, -1):
+                mine[off[b]:off[b] + nr[b] * w[b]] = True
+        assert np.abs(arenas[r] - ref)[mask & mine].max() / np.abs(ref).max() < 1e-12
+    # mutation: drop the waits for the LAST chunk from a rank's program -> some launch touches the
+    # top level's block columns unordered against the unpack of its reduce-scatter
+    class Mutant:
+        def __init__(self, g, drop):
+            self.g, self.drop, self.rank = g, drop, g.rank
+        def program(self, name):
+            t = self.g.program(name)
+            if name == "launches":
+                t = t.copy()
+                t[:, 8:12][t[:, 8:12] == self.drop] = -1
+            return t
+        def sym(self, name):
+            return self.g.sym(name)
+    assert any(ts.dag_violations(Mutant(g, recs[-1]))[0] for g in fs), "the DAG check must notice a missing chunk wait"
+    for g in fs:
+        g.close()
