@@ -57,9 +57,15 @@ for rep in range(2):   # second repetition is the measurement
         ttop = (time.perf_counter() - t0) * 1e3
 ex = f.program("exchanges") if w > 1 else []
 vol = {int(k): 0 for k in (0, 1, 2)}
+xit = f.program("xitems") if w > 1 else []
 for kind, first, nit, elems, chunk in (ex.tolist() if w > 1 else []):
-    if kind in vol:
-        vol[kind] += elems
+    # (elems is the END of the exchange's region in the buffer: the volume is counted from the items)
+    if kind == 0:
+        vol[0] += elems
+    elif kind == 1:
+        vol[1] += chunk * w
+    elif kind == 2:
+        vol[2] += int(xit[first:first + nit, 3].sum())
 si = f.sym_info()
 print(json.dumps({"config": cfg_name, "width": w, "rank": r, "top": "distributed" if dist else "replicated",
                   "subtree_ms": round(tsub, 2), "top_ms": None if ttop is None else round(ttop, 2),
