@@ -124,14 +124,14 @@ def attach_pmc(roof, workload):
     be read from inside this process); the committed per-launch summary of the SAME command is
     quoted when it was taken on this very workload."""
     try:
-        path = os.path.join(ROOT, "profiles", "r03", PROFILE_DIRS[workload], "summary.json")
+        path = os.path.join(ROOT, "profiles", "r04", PROFILE_DIRS[workload], "summary.json")
         with open(path) as fh:
             pmc = json.load(fh)
         k = pmc.get("kernels", {}).get(roof["kernel"])
         if pmc.get("workload") == workload and k:
             roof["traffic"] = round(k["hbm_bytes_per_launch"])
             roof["traffic_unit"] = ("bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, "
-                                    f"profiles/r03/{PROFILE_DIRS[workload]}/summary.json)")
+                                    f"profiles/r04/{PROFILE_DIRS[workload]}/summary.json)")
             roof["algorithmic_bytes_per_launch"] = round(k["algorithmic_bytes_per_launch"])
             if k.get("mfma_util_percent") is not None:
                 roof["mfma_util_percent"] = round(k["mfma_util_percent"], 1)
