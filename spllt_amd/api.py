@@ -224,9 +224,13 @@ class Factorization:
         return {"submit_ms": s.value, "device_ms": d.value, "h2d_ms": h.value,
                 "launches": nl.value}
 
-    def get_factor(self):
+    def get_factor(self, out=None):
+        """the factor's arena on the host; out: an existing float64 array of that length to fill
+        (a fresh one pays its page faults during the copy)"""
         arena = self.sym_info()["arena"]
-        out = np.zeros(max(arena, 1), dtype=np.float64)
+        if out is None:
+            out = np.zeros(max(arena, 1), dtype=np.float64)
+        assert out.dtype == np.float64 and out.size >= arena and out.flags["C_CONTIGUOUS"]
         rc = self.lib.spllt_hip_get_factor(self.fkeep, _dp(out), arena)
         if rc < 0:
             raise SplltError("spllt_hip_get_factor", rc, self.last_error())
