@@ -22,6 +22,7 @@ The engine's program lists the exchanges (exchange_plan); run_exchange is the co
 torch is used only for device memory and torch.distributed (plumbing).
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -138,6 +139,7 @@ class DistributedFactorization:
         import torch.distributed as dist
         from . import api
         self.rank, self.world, self.group = rank, world, group
+        driver_arg = driver
         if driver is None:
             driver = os.environ.get("SPLLT_MG_DRIVER") or (
                 "library" if (world > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl") else "python")
@@ -163,10 +165,36 @@ class DistributedFactorization:
                 self.scratch = torch.empty(chunk, dtype=torch.float64, device="cuda")
         self.dist_top = any(st[0] == X_REDUCE_OWNER for st in self.plan)
         if self.driver == "library":
-            # the library owns the exchange buffer and runs every collective itself, on its own stream
-            if comm is None:
-                comm, self._comm_destroy = make_rccl_communicator(rank, world, group)
-            self.f.set_communicator(comm)
+            # the library runs every collective itself, on its own streams.  When the driver was
+            # chosen by default (not asked for), a rank that cannot set the communicator up makes
+            # EVERY rank fall back to the Python driver -- agreed through the process group, so that
+            # nobody is left alone in a collective.
+            explicit = driver_arg is not None or bool(os.environ.get("SPLLT_MG_DRIVER"))
+            ok, why = 1, ""
+            try:
+                if comm is None:
+                    comm, self._comm_destroy = make_rccl_communicator(rank, world, group)
+                self.f.set_communicator(comm)
+            except Exception as e:   # noqa: BLE001 - decided collectively below
+                if explicit:
+                    raise
+                ok, why = 0, repr(e)[:200]
+            if not explicit and world > 1 and dist.is_initialized():
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                if rank == 0:
+                    print(f"spllt-hip: library RCCL driver not available ({why or 'another rank failed'}): "
+                          "falling back to the torch.distributed driver", file=sys.stderr, flush=True)
+                try:
+                    self.f.set_communicator(0)
+                except Exception:   # noqa: BLE001
+                    pass
+                if self._comm_destroy is not None:
+                    self._comm_destroy()
+                    self._comm_destroy = None
+                self.driver = "python"
         self.stream_ordered = (world > 1 and dist.is_initialized() and
                                (dist.get_backend(group) == "nccl" or
                                 bool(os.environ.get("SPLLT_FORCE_STREAM_ORDERED"))))   # (tests: gloo)
