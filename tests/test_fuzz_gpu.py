@@ -23,8 +23,12 @@ def _random_spd(rng, n, density):
 
 
 @pytest.mark.parametrize("seed", range(64))
-def test_fuzz_factor_and_solve(seed):
+def test_fuzz_factor_and_solve(seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
+    # every third case with chain blocks of four panels (k_chain_block + k_trsm_rows: ragged panel
+    # widths that are no multiple of 4, block columns of 1-40 panels), the graph replays and eager launches in turn
+    monkeypatch.setenv("SPLLT_CHAIN4", "1" if seed % 3 == 2 else "0")
+    monkeypatch.setenv("SPLLT_HIP_GRAPH", str(seed % 4 - 1) if seed % 4 else "-1")
     kind = seed % 4
     if kind == 0:
         A = matgen.nd_like(tuple(int(x) for x in rng.integers(4, 11, size=3)), int(rng.integers(1, 3)))
@@ -57,9 +61,13 @@ def test_fuzz_factor_and_solve(seed):
 @pytest.mark.parametrize("flags", [0, 2, 64, 2048])
 @pytest.mark.parametrize("cb", [None, 40, 256])
 @pytest.mark.parametrize("nb,pw", [(48, 5), (48, 24), (100, 10), (100, 40), (130, 48), (33, 12)])
-def test_ragged_panels_in_every_engine_variant(flags, cb, nb, pw):
+@pytest.mark.parametrize("chain4", [0, 1])
+def test_ragged_panels_in_every_engine_variant(flags, cb, nb, pw, chain4, monkeypatch):
     """panel widths that are no multiple of 16 (or 4) and do not divide nb, in
-    every engine variant and with sub-tiles that end inside a block column"""
+    every engine variant and with sub-tiles that end inside a block column; with one panel per
+    chain step and with chain blocks of four panels (k_chain_block / k_trsm_rows on 5-, 10-, 12-,
+    24-, 40- and 48-wide panels)"""
+    monkeypatch.setenv("SPLLT_CHAIN4", str(chain4))
     A = matgen.fe27((5, 4, 4), 3)
     f, val = make_case(A, nb=nb, nemin=4, panel_width=pw, engine_flags=flags, chain_block=cb)
     got = f.factor(val).wait().get_factor()
@@ -115,11 +123,13 @@ def _partitioned_factor_and_solve(A, world, nb, nemin, pw, flags=0):
     return fs, val, got, B
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_fuzz_partitioned_factor_and_solve(seed):
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_partitioned_factor_and_solve(seed, monkeypatch):
     """subtree partition over 2..5 ranks (some may own nothing, the top tree may be
     one node) on random shapes: L of every rank against the oracle on the block
-    columns it holds, the partitioned solve against the residual bar"""
+    columns it holds, the partitioned solve against the residual bar; every other case with chain
+    blocks of four panels (the distributed top tree's owners run k_chain_block / k_trsm_rows)"""
+    monkeypatch.setenv("SPLLT_CHAIN4", str(seed % 2))
     rng = np.random.default_rng(2000 + seed)
     if seed % 3 == 0:
         A = matgen.nd_like(tuple(int(x) for x in rng.integers(5, 11, size=3)), int(rng.integers(1, 3)))
