@@ -249,7 +249,8 @@ int spllt_hip_continue(void *fkeep);
  * "map_keep" (uint8 per val->L map entry: scattered on this rank) */
 int64_t spllt_hip_partition_get(void *fkeep, const char *name, void *buf, int64_t capacity_bytes);
 
-/* spllt_factor with val already resident in HBM (device pointer) */
+/* spllt_factor with val already resident in HBM (device pointer).  val_dev must stay valid and
+ * unchanged until spllt_hip_wait returns: the factorization reads it in place. */
 void spllt_hip_factor_dev(void *akeep, void *fkeep, spllt_options_t *options, int nnz,
                           const double *val_dev, spllt_inform_t *info);
 /* wait for ONE factorization and return its flag (spllt_wait() has no way to) */

@@ -934,7 +934,7 @@ int Engine::finish_enqueue() {
 
 int Engine::enqueue_program() {
   const Symbolic& S = *S_;
-  if (graph_mode_ > 0 && prog_.exchanges.empty() && !opt_.poison_lds) {
+  if (replays_graph()) {
     int rc = build_graph(graph_mode_);
     if (rc) return rc;
     stats_.launches = (int)prog_.launches.size() + 1;
@@ -955,7 +955,7 @@ int Engine::enqueue_program() {
   const int big = INT_MAX;
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
-  launch_scatter_val(stream_, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
+  launch_scatter_val(stream_, d_L_, val_src_ ? val_src_ : d_val_, d_map_dst_, d_map_src_, nmap_);
   if (!prog_.exchanges.empty()) {
     // A partitioned program may have an exchange as its FIRST launch on a stream other than this one
     // (a rank that owns no subtree: its phase 1 is empty, and the per-level reduce-scatters of a
@@ -1217,8 +1217,17 @@ int Engine::factor_async_dev(const double* val_dev, int64_t nnz) {
   double t0 = now_ms();
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipEventRecord(ev0_, stream_), "event");
-  if (val_dev != d_val_)
-    HIPCHK(hipMemcpyAsync(d_val_, val_dev, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, stream_), "val D2D");
+  // Eager launches read the caller's device array directly (it must stay valid and unchanged until
+  // spllt_hip_wait: include/spllt_hip.h) -- the copy into the engine's own buffer was 88 MB each way
+  // on the bench workload, 60 us in front of every factorization.  A graph replay has the engine's
+  // buffer baked into its nodes: there the values are copied.
+  val_src_ = nullptr;
+  if (val_dev != d_val_) {
+    if (replays_graph())
+      HIPCHK(hipMemcpyAsync(d_val_, val_dev, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, stream_), "val D2D");
+    else
+      val_src_ = val_dev;
+  }
   HIPCHK(hipEventRecord(ev_h2d_, stream_), "event");
   int rc = enqueue_program();
   if (rc) return rc;
@@ -1235,6 +1244,7 @@ int Engine::factor_async(const double* val_host, int64_t nnz) {
   double t0 = now_ms();
   HIPCHK(hipSetDevice(device_), "hipSetDevice");
   HIPCHK(hipEventRecord(ev0_, stream_), "event");
+  val_src_ = nullptr;            // (the values go through the engine's own buffer)
   crumb("factor: H2D of val");
   // test hook (tests/test_gpu_parity.py::test_submission_deadline): a runtime call that sits
   if (const char* e = std::getenv("SPLLT_HIP_TEST_STALL_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(e)));

@@ -185,6 +185,8 @@ class Engine {
   bool comm_rehearsal_ = false;   // set_communicator accepted a one-rank stand-in (SPLLT_HIP_COMM_REHEARSAL): results are not the factor
   mutable bool localize_failed_ = false;
   int graph_mode_ = 0;
+  const double* val_src_ = nullptr;   // eager factor_async_dev: the caller's device array, read in place (else d_val_)
+  bool replays_graph() const { return graph_mode_ > 0 && prog_.exchanges.empty() && !opt_.poison_lds; }
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
   bool pending_ = false;
