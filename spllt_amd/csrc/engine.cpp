@@ -640,6 +640,27 @@ int Engine::upload() {
     nmap_ = S.nnzA;
     HIPCHK(dev_upload(&d_map_dst_, S.map_dst), "upload map_dst");
     HIPCHK(dev_upload(&d_map_src_, S.map_src), "upload map_src");
+    // the same map bucketed by 32 KB chunks of the arena, for the one-pass initialisation
+    // (k_init_arena): a counting sort, two passes over the map
+    static const bool one_pass = [] { const char* e = std::getenv("SPLLT_INIT_ONE_PASS"); return !(e && std::atoi(e) == 0); }();
+    if (one_pass && S.arena > 0 && S.nnzA <= INT_MAX) {
+      const int64_t nch = (S.arena + kInitChunk - 1) / kInitChunk;
+      std::vector<int64_t> cptr((size_t)nch + 1, 0);
+      for (int64_t d : S.map_dst) cptr[(size_t)(d / kInitChunk) + 1]++;
+      for (int64_t c = 0; c < nch; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
+      std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
+      std::vector<unsigned short> loc(S.map_dst.size());
+      std::vector<int> src(S.map_dst.size());
+      for (size_t i = 0; i < S.map_dst.size(); ++i) {
+        const int64_t d = S.map_dst[i];
+        const int64_t at = fill[(size_t)(d / kInitChunk)]++;
+        loc[(size_t)at] = (unsigned short)(d % kInitChunk);
+        src[(size_t)at] = (int)S.map_src[i];
+      }
+      HIPCHK(dev_upload(&d_init_cptr_, cptr), "upload init map");
+      HIPCHK(dev_upload(&d_init_loc_, loc), "upload init map");
+      HIPCHK(dev_upload(&d_init_src_, src), "upload init map");
+    }
   }
   std::vector<int64_t> off(S.nbcol());
   std::vector<int> w(S.nbcol());
@@ -942,10 +963,11 @@ int Engine::enqueue_program() {
     awaiting_exchange_ = false;
     return 0;
   }
+  const bool one_pass_init = opt_.nranks <= 1 && d_init_cptr_ != nullptr;
   if (opt_.nranks > 1) {
     for (const auto& r : zero_ranges_)
       HIPCHK(hipMemsetAsync(d_L_ + r.first, 0, sizeof(double) * (size_t)r.second, stream_), "memset arena");
-  } else {
+  } else if (!one_pass_init) {
     HIPCHK(hipMemsetAsync(d_L_, 0, sizeof(double) * (size_t)S.arena, stream_), "memset arena");
   }
   // the "last reader" counters of the fused panel launches return to zero by themselves; a
@@ -955,7 +977,10 @@ int Engine::enqueue_program() {
   const int big = INT_MAX;
   *h_flag_ = big;
   HIPCHK(hipMemcpyAsync(d_flag_, h_flag_, sizeof(int), hipMemcpyHostToDevice, stream_), "flag init");
-  launch_scatter_val(stream_, d_L_, val_src_ ? val_src_ : d_val_, d_map_dst_, d_map_src_, nmap_);
+  if (one_pass_init)
+    launch_init_arena(stream_, d_L_, S.arena, val_src_ ? val_src_ : d_val_, d_init_cptr_, d_init_loc_, d_init_src_);
+  else
+    launch_scatter_val(stream_, d_L_, val_src_ ? val_src_ : d_val_, d_map_dst_, d_map_src_, nmap_);
   if (!prog_.exchanges.empty()) {
     // A partitioned program may have an exchange as its FIRST launch on a stream other than this one
     // (a rank that owns no subtree: its phase 1 is empty, and the per-level reduce-scatters of a

@@ -219,6 +219,9 @@ class Engine {
   double* d_val_ = nullptr;
   double* d_dinv_ = nullptr;
   int64_t* d_map_dst_ = nullptr;
+  int64_t* d_init_cptr_ = nullptr;          // val -> L map bucketed by arena chunk (k_init_arena; single GPU)
+  unsigned short* d_init_loc_ = nullptr;
+  int* d_init_src_ = nullptr;
   int64_t* d_map_src_ = nullptr;
   int64_t* d_bc_off_ = nullptr;
   int* d_bc_w_ = nullptr;

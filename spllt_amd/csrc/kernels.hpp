@@ -24,6 +24,12 @@ struct LaunchSink {
 
 void launch_scatter_val(const LaunchSink& st, double* L, const double* val, const int64_t* dst,
                         const int64_t* src, int64_t n);
+// the arena cleared and A copied in, in one pass (cptr / loc / src: the val -> L map bucketed by
+// chunks of kInitChunk doubles of the arena: entries of chunk c are [cptr[c], cptr[c + 1]), loc = the
+// entry's position inside the chunk, src = its index in val)
+constexpr int kInitChunk = 4096;
+void launch_init_arena(const LaunchSink& st, double* L, int64_t arena, const double* val, const int64_t* cptr,
+                       const unsigned short* loc, const int* src);
 // (unit0 = host copy of units[0]: travels with the kernel arguments)
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag, const PotrfUnit& unit0);
