@@ -157,6 +157,13 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * config 1: there the host's submission is as long as the device's work), the DAG replay up to
  * 40 GFLOP, eager above (on ROCm 7.2 hipGraphLaunch submits nothing before all nodes are
  * enqueued: 25.1 / 24.4 ms against 23.7 eager on the 650 launches of the bench workload).
+ * Bit 18 / bit 19 = small subtrees as single device tasks on / off (L_SUBTREE, k_subtree: one
+ * workgroup factorizes a whole subtree of one-panel nodes in post-order, what leaves the subtree
+ * goes through a private generated element and reaches the ancestors in ONE extend-add from the
+ * subtree's root -- the reference's pruned-subtree task, src/spllt_factorization_mod.F90:39-261).
+ * Default off: slower than the level-batched launches at every size and budget measured
+ * (profiles/r04/subtree_tasks_ab.txt); env SPLLT_SUBTREES=1, SPLLT_SUBTREE_US=<modelled us per task>.
+ * Single-GPU, non-deterministic engines only.
  * Bits 2-5 selected round-1 experiments that have been removed.
  * Every variant produces the same factor (tests/test_gpu_parity.py). */
 int spllt_hip_set_engine(void *fkeep, int panel_width, int tile, int flags);

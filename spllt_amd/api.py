@@ -32,6 +32,10 @@ CHAIN_UNIT_DTYPE = np.dtype([("off", "<i8"), ("winv_off", "<i8"), ("ld", "<i4"),
 PANEL_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"),
                              ("ld", "<i4"), ("c0", "<i4"), ("pn", "<i4"), ("next_pn", "<i4"),
                              ("nrow", "<i4"), ("gcol", "<i4"), ("ntile", "<i4"), ("pad_", "<i4")])
+SUB_TASK_DTYPE = np.dtype([("g_off", "<i8"), ("node_first", "<i4"), ("node_count", "<i4"), ("g_n", "<i4"),
+                           ("pad_", "<i4")])
+SUB_NODE_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("w", "<i4"), ("nrow", "<i4"), ("gcol", "<i4"),
+                           ("unit_first", "<i4"), ("unit_count", "<i4"), ("root", "<i4")])
 GATHER_ITEM_DTYPE = np.dtype([("buf_off", "<i8"), ("relrow_off", "<i8"), ("gcol_off", "<i8"), ("ld", "<i4"),
                               ("i0", "<i4"), ("i1", "<i4"), ("j0", "<i4"), ("j1", "<i4"),
                               ("diag_shift", "<i4"), ("lower", "<i4"), ("pad_", "<i4")])
@@ -163,13 +167,17 @@ class Factorization:
             return raw.view(CHAIN_UNIT_DTYPE)
         if name == "panels":
             return raw.view(PANEL_UNIT_DTYPE)
+        if name == "sub_tasks":
+            return raw.view(SUB_TASK_DTYPE)
+        if name == "sub_nodes":
+            return raw.view(SUB_NODE_DTYPE)
         if name == "exchanges":
             return raw.view(np.int64).reshape(-1, 5)
         if name == "xitems":
             return raw.view(np.int64).reshape(-1, 6)
         if name == "xbuf_elems":
             return int(raw.view(np.int64)[0])
-        if name in ("chain_block", "scratch_size", "panel_width"):
+        if name in ("chain_block", "scratch_size", "panel_width", "gen_size"):
             return int(raw.view(np.int64)[0])
         if name == "gather_tiles":
             return raw.view(GATHER_TILE_DTYPE)

@@ -581,6 +581,8 @@ int spllt_hip_set_engine(void* fkeep, int panel_width, int tile, int flags) {
   if (flags & 32768) f->eo.graph = 1;       // bit 15 / 16: HIP-graph replay, one chain in program order /
   if (flags & 65536) f->eo.graph = 2;       // the DAG of the multi-stream program
   if (flags & 131072) f->eo.graph = 0;      // bit 17: eager launches
+  if (flags & 262144) f->eo.subtrees = 1;   // bit 18 / 19: small subtrees as single device tasks (L_SUBTREE)
+  if (flags & 524288) f->eo.subtrees = 0;   // on / off
   return 0;
 }
 
@@ -810,6 +812,9 @@ int64_t spllt_hip_program_get(void* fkeep, const char* name, void* buf, int64_t 
   }
   if (k == "xbuf_elems") return raw(&P->xbuf_elems, sizeof(int64_t));
   if (k == "panels") return raw(P->panel_units.data(), P->panel_units.size() * sizeof(PanelUnit));
+  if (k == "sub_tasks") return raw(P->sub_tasks.data(), P->sub_tasks.size() * sizeof(SubTask));
+  if (k == "sub_nodes") return raw(P->sub_nodes.data(), P->sub_nodes.size() * sizeof(SubNode));
+  if (k == "gen_size") { int64_t v = P->gen_size; return raw(&v, sizeof v); }
   if (k == "chains") return raw(P->chain_units.data(), P->chain_units.size() * sizeof(ChainUnit));
   if (k == "chain_block") { int64_t v = P->cb; return raw(&v, sizeof v); }
   if (k == "panel_width") { int64_t v = P->pw; return raw(&v, sizeof v); }

@@ -329,6 +329,7 @@ ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
   so.slice_between = opt.slice_between;
   so.deterministic = opt.deterministic;
   so.fused_panel = opt.fused_panel;
+  if (opt.subtrees >= 0) so.subtrees = opt.subtrees != 0;
   const bool lb = latency_bound(S, std::min(opt.pw, kPanelMax));
   // CU reservation (bulk / far streams masked off the last CUs): OFF by default since round 4.  It
   // bought 24.9 -> 24.4 ms in round 2 and buys 23.35 -> 23.2 ms now (0.6 %, profiles/r04/ab_cu_reserve.txt),
@@ -617,6 +618,12 @@ int Engine::upload() {
   // the POTRF kernels store the lower triangle of an inverted panel only; what lies above the
   // diagonal of a slot is zero from here on (nothing else writes there)
   HIPCHK(hipMemset(d_dinv_, 0, sizeof(double) * (size_t)(std::max<int64_t>(1, prog_.dinv_size) + 32)), "hipMemset(dinv)");
+  if (prog_.gen_size > 0) {
+    // the generated elements of the subtree tasks: zero here, and zero again after every factorization
+    // (the root of a subtree clears what it adds to its ancestors)
+    HIPCHK(dalloc((void**)&d_gen_, sizeof(double) * (size_t)prog_.gen_size), "hipMalloc(generated elements)");
+    HIPCHK(hipMemset(d_gen_, 0, sizeof(double) * (size_t)prog_.gen_size), "hipMemset(generated elements)");
+  }
   if (opt_.nranks > 1) {
     // this rank scatters A only into its own subtrees; the top tree's values
     // are contributed by rank 0 alone so that the cross-rank sum holds them once
@@ -688,6 +695,8 @@ int Engine::upload() {
   tab.add(&d_tiles_, prog_.tiles);
   tab.add(&d_chain_, prog_.chain_units);
   tab.add(&d_panel_, prog_.panel_units);
+  tab.add(&d_sub_tasks_, prog_.sub_tasks);
+  tab.add(&d_sub_nodes_, prog_.sub_nodes);
   const std::vector<int> zeros(2 * std::max<size_t>(1, prog_.panel_units.size()), 0);
   tab.add(&d_panel_cnt_, zeros);
   tab.add(&d_relpos_, prog_.relpos);
@@ -792,6 +801,9 @@ void Engine::emit_kernel(const Launch& l, const LaunchSink& sink, bool multi) {
   } else if (l.kind == L_TRSM4) {
     launch_trsm_rows(sink, d_tiles_ + l.first, l.count, d_units_, d_L_, d_dinv_, prog_.pw,
                      (multi && l.stream == ST_CHAIN) ? chain_prio_ : 0);
+  } else if (l.kind == L_SUBTREE) {
+    launch_subtree(sink, d_sub_tasks_ + l.first, l.count, d_sub_nodes_, d_units_, d_relpos_, d_rlist_, d_L_, d_dinv_,
+                   d_gen_, d_flag_);
   } else if (l.kind == L_PANEL) {
     launch_panel(sink, d_tiles_ + l.first, l.count, d_panel_, d_L_, d_dinv_, d_panel_cnt_, d_flag_);
   } else if (l.kind == L_GATHER) {
@@ -850,7 +862,8 @@ int Engine::build_graph(int mode) {
   };
   hipGraphNode_t n_cnt = nullptr, n_flag = nullptr;
   std::vector<hipGraphNode_t> pre;
-  {
+  const bool one_pass_init = d_init_cptr_ != nullptr;     // k_init_arena clears as it copies
+  if (!one_pass_init) {
     // (in pieces of 4 GiB: 32-bit element counts somewhere below would not be a surprise)
     const size_t words = (size_t)S.arena * 2, piece = (size_t)1 << 30;
     for (size_t o = 0; o < words; o += piece) {
@@ -871,7 +884,10 @@ int Engine::build_graph(int mode) {
     sink.graph = graph_;
     sink.deps = pre.data();
     sink.ndeps = pre.size();
-    launch_scatter_val(sink, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
+    if (one_pass_init)
+      launch_init_arena(sink, d_L_, S.arena, d_val_, d_init_cptr_, d_init_loc_, d_init_src_);
+    else
+      launch_scatter_val(sink, d_L_, d_val_, d_map_dst_, d_map_src_, nmap_);
     HIPCHK(sink.err, "graph scatter node");
     n_scatter = sink.node;
     if (!n_scatter) {     // (no entries: an empty node keeps the prefix in one piece)
@@ -981,7 +997,8 @@ int Engine::enqueue_program() {
     launch_init_arena(stream_, d_L_, S.arena, val_src_ ? val_src_ : d_val_, d_init_cptr_, d_init_loc_, d_init_src_);
   else
     launch_scatter_val(stream_, d_L_, val_src_ ? val_src_ : d_val_, d_map_dst_, d_map_src_, nmap_);
-  if (!prog_.exchanges.empty()) {
+  if (!prog_.exchanges.empty() || !prog_.sub_tasks.empty()) {
+    // (the subtree tasks are the first launch of the side stream and wait for nothing else.)
     // A partitioned program may have an exchange as its FIRST launch on a stream other than this one
     // (a rank that owns no subtree: its phase 1 is empty, and the per-level reduce-scatters of a
     // distributed top tree run on the side stream): nothing would order its pack behind the clearing

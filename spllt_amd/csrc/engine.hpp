@@ -44,6 +44,7 @@ struct EngineOptions {
                            // problem is latency-bound (schedule.hpp), else 0)
   int zones = -1;          // zone pipeline of the inter-node updates (1 / 0; -1: when latency-bound)
   int rank = 0, nranks = 1;  // multi-GPU subtree partition (nranks > 1: two-phase program)
+  int subtrees = -1;       // small subtrees as single device tasks (L_SUBTREE): 1 / 0; -1: the default (off)
   int graph = -1;          // HIP-graph replay of the factorization (single GPU): 0 eager launches, 1 one
                            // chain of kernel nodes in program order, 2 the DAG of the multi-stream
                            // program, -1 by problem size (env SPLLT_HIP_GRAPH overrides)
@@ -231,6 +232,9 @@ class Engine {
   UpdTile* d_tiles_ = nullptr;
   ChainUnit* d_chain_ = nullptr;
   PanelUnit* d_panel_ = nullptr;
+  SubTask* d_sub_tasks_ = nullptr;   // L_SUBTREE: one workgroup per small subtree
+  SubNode* d_sub_nodes_ = nullptr;
+  double* d_gen_ = nullptr;          // generated elements of the subtree tasks (zero between factorizations)
   int* d_panel_cnt_ = nullptr;     // two "last reader" counters per panel unit (zero between launches)
   GatherTile* d_gtiles_ = nullptr;
   GatherItem* d_gitems_ = nullptr;

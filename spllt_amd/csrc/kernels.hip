@@ -1076,6 +1076,134 @@ __global__ __launch_bounds__(kPanelThreads) void k_panel(const UpdTile* __restri
 }
 
 // ---------------------------------------------------------------------------
+// A whole small subtree in ONE workgroup (SubTask; L_SUBTREE): the reference's subtree task
+// (a20-a25: spllt_subtree_factorize, src/spllt_factorization_mod.F90:196-261; its kernels
+// kernels_mod:97-821).  The nodes of the task are walked in post-order; every node has one block
+// column of at most one panel:
+//   1. L_ss = chol(A_ss), W = inv(L_ss)                       (potrf64: a11)
+//   2. X = A_below W^T, 64 rows at a time                      (a12)
+//   3. its update units, one 64 x 64 tile X_I X_J^T at a time (a16-a19):
+//        MODE_SCATTER  into a node of the same subtree (only this workgroup touches it before the
+//                      launch ends) or, from the ROOT, into the ancestors above the subtree
+//        MODE_GEN      what leaves the subtree from a node below the root: into the subtree's
+//                      generated element (packed lower triangle over the root's rows below its
+//                      columns, a few hundred KB: cache-resident while the subtree is worked on)
+//      the root's tiles take the generated element along: dest -= X_I X_J^T + G_IJ, G_IJ = 0 --
+//      the ONE extend-add of the subtree (factorization_mod:39-191); the scratch is zero again when
+//      the launch ends.
+// All adds are atomics without return (the workgroup does not wait for them); a fence + barrier
+// per node makes them visible to the loads of the nodes that follow.
+// LDS: PotrfShared only (T = staging of A / X_I, X = W, then X_J): two workgroups per CU.
+// ---------------------------------------------------------------------------
+constexpr int kSubThreads = 512;
+
+__global__ __launch_bounds__(kSubThreads) void k_subtree(const SubTask* __restrict__ tasks,
+                                                         const SubNode* __restrict__ nodes,
+                                                         const UpdUnit* __restrict__ units,
+                                                         const int* __restrict__ relpos,
+                                                         const int* __restrict__ rlist,
+                                                         double* __restrict__ L,
+                                                         double* __restrict__ dinv,
+                                                         double* __restrict__ G,
+                                                         int* __restrict__ flag) {
+  __shared__ PotrfShared sh;
+  const SubTask T = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+  const int s = wave >> 1, jb0 = (wave & 1) * 2;   // this wave's 16-row strip and two 16-column blocks
+  for (int ni = 0; ni < T.node_count; ++ni) {
+    const SubNode nd = nodes[T.node_first + ni];
+    double* A = L + nd.off;
+    const int w = nd.w, m = nd.nrow, ld = nd.w;
+    // ---- 1. the diagonal block ----------------------------------------------------------
+    potrf64(sh, A, ld, w, dinv + nd.dinv_off, w, nd.gcol, 8, flag);
+    __syncthreads();
+    // ---- 2. the rows below ---------------------------------------------------------------
+    for (int r0 = w; r0 < m; r0 += 64) {
+      const int nr = min(64, m - r0);
+      stage_block(sh.T, A + (int64_t)r0 * ld, ld, nr, w, tid);
+      __syncthreads();
+      d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+      mma_64(sh.T, sh.X, s, jb0, lane, a0, a1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = s * 16 + lq + 4 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = (jb0 + h) * 16 + lr;
+          if (i < nr && j < w) A[(int64_t)(r0 + i) * ld + j] = h ? a1[r] : a0[r];
+        }
+      }
+      __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- 3. the update units ---------------------------------------------------------------
+    const bool with_gen = nd.root != 0 && T.g_n > 0;
+    for (int ui = 0; ui < nd.unit_count; ++ui) {
+      const UpdUnit u = units[nd.unit_first + ui];
+      const bool gen = u.mode == MODE_GEN;
+      const int nti = (u.M + 63) >> 6, ntj = (u.N + 63) >> 6;
+      double* dst = (gen ? G : L) + u.d_off;
+      for (int tj = 0; tj < ntj; ++tj) {
+        const int c0 = u.src_c0 + 64 * tj, nc = min(64, u.N - 64 * tj);
+        stage_block(sh.X, A + (int64_t)c0 * ld, ld, nc, w, tid);
+        // the columns of this wave's entries in the destination
+        int dcol[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = (jb0 + h) * 16 + lr;
+          const int64_t at = u.gcol_off + 64 * tj + (j < nc ? j : nc - 1);
+          dcol[h] = gen ? relpos[at] : rlist[at] - u.d_col0;
+        }
+        for (int ti = 0; ti < nti; ++ti) {
+          const int r0 = u.src_r0 + 64 * ti, nr = min(64, u.M - 64 * ti);
+          if (r0 + nr - 1 < c0) continue;                  // entirely above the diagonal
+          const double* Sa = sh.X;
+          if (r0 != c0 || nr != nc) {                      // (the diagonal tile of a square corner: X_I = X_J)
+            stage_block(sh.T, A + (int64_t)r0 * ld, ld, nr, w, tid);
+            Sa = sh.T;
+          }
+          int drow[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = s * 16 + lq + 4 * r;
+            drow[r] = relpos[u.relrow_off + 64 * ti + (i < nr ? i : nr - 1)] - (gen ? 0 : u.d_row0);
+          }
+          __syncthreads();
+          d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+          mma_64(Sa, sh.X, s, jb0, lane, a0, a1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = s * 16 + lq + 4 * r;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int j = (jb0 + h) * 16 + lr;
+              if (i >= nr || j >= nc || r0 + i < c0 + j) continue;
+              double v = h ? a1[r] : a0[r];
+              if (gen) {
+                unsafeAtomicAdd(dst + (int64_t)drow[r] * (drow[r] + 1) / 2 + dcol[h], -v);
+              } else {
+                if (with_gen) {
+                  const int gi = r0 + i - w, gj = c0 + j - w;
+                  double* q = G + T.g_off + (int64_t)gi * (gi + 1) / 2 + gj;
+                  v -= *q;
+                  *q = 0.0;
+                }
+                unsafeAtomicAdd(dst + (int64_t)drow[r] * u.d_ld + dcol[h], -v);
+              }
+            }
+          }
+          __syncthreads();
+        }
+        __syncthreads();
+      }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // One step of the panel chain for a CHAIN BLOCK of up to four panels (ChainUnit with pn = its
 // width cw <= 4 pw), one workgroup: the whole cw x cw diagonal block of a block column is
 // factored here, panel by panel, right-looking, with nothing but this workgroup's barriers
@@ -2454,6 +2582,13 @@ void launch_chain_block(const LaunchSink& st, const ChainUnit* units, int64_t co
     attr_dev = dev;
   }
   emit(st, k_chain_block, dim3((unsigned)count), dim3(kPanelThreads), lds, units, L, dinv, flag, pw, unit0);
+}
+
+void launch_subtree(const LaunchSink& st, const SubTask* tasks, int64_t count, const SubNode* nodes,
+                    const UpdUnit* units, const int* relpos, const int* rlist, double* L, double* dinv, double* gen,
+                    int* flag) {
+  if (count <= 0) return;
+  emit(st, k_subtree, dim3((unsigned)count), dim3(kSubThreads), 0, tasks, nodes, units, relpos, rlist, L, dinv, gen, flag);
 }
 
 void launch_trsm_rows(const LaunchSink& st, const UpdTile* tiles, int64_t count, const UpdUnit* units, double* L,

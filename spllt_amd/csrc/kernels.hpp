@@ -33,6 +33,11 @@ void launch_init_arena(const LaunchSink& st, double* L, int64_t arena, const dou
 // (unit0 = host copy of units[0]: travels with the kernel arguments)
 void launch_potrf(hipStream_t st, const PotrfUnit* units, int64_t count, double* L, double* dinv,
                   int* flag, const PotrfUnit& unit0);
+// one small subtree per workgroup (SubTask): its nodes in post-order, what leaves the subtree through the
+// generated-element scratch `gen` (zero before and after)
+void launch_subtree(const LaunchSink& st, const SubTask* tasks, int64_t count, const SubNode* nodes,
+                    const UpdUnit* units, const int* relpos, const int* rlist, double* L, double* dinv, double* gen,
+                    int* flag);
 // one step of the panel chain per workgroup (ChainUnit): POTRF of the panel + its inverse
 void launch_chain_panel(const LaunchSink& st, const ChainUnit* units, int64_t count, double* L, double* dinv,
                         int* flag, const ChainUnit& unit0);

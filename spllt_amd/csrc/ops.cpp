@@ -156,6 +156,7 @@ int spllt_factor_diag_block_hip(void* stream, int m, int n, double* bc, int* dev
   OpsBatch B;
   ScheduleOptions so;
   so.lookahead = false;  // one stream, program order
+  so.subtrees = false;   // (the batch runner knows the panel-chain launches only)
   build_program(S, so, B.P);
   B.bc_off = {S.bcols[0].off};
   B.bc_w = {n};

@@ -252,13 +252,14 @@ struct Builder {
   int64_t xbcast_base = 0;   // offset of the broadcast area in the exchange buffer (behind the reduce regions)
   bool mine(int b) const { return !dist2 || opt.top_owner[b] == opt.rank; }
 
-  void between_templates(int s, std::vector<UpdUnit>& out) {
+  // last >= 0: only the ancestors up to node `last` (the root of s's subtree task)
+  void between_templates(int s, std::vector<UpdUnit>& out, int last = -1) {
     const int nn = S.nnodes;
     const int m = S.nrow(s);
     const int* idx = S.rows(s);
     int cptr = S.ncol(s);
     int a = S.sparent[s];
-    while (a < nn && cptr < m) {
+    while (a < nn && cptr < m && (last < 0 || a <= last)) {
       const int asa = S.sptr[a], aen = S.sptr[a + 1] - 1;
       while (cptr < m && idx[cptr] < asa) cptr++;
       if (cptr >= m) break;
@@ -467,6 +468,156 @@ struct Builder {
     P.launches.push_back(G);                 // same stream, in order behind the products
   }
 
+  // ---------------------------------------------------------------------------------------------
+  // Subtree tasks (L_SUBTREE).  The reference hands every pruned subtree to ONE task that factorizes
+  // its nodes in post-order, keeps what leaves the subtree in a private generated element and adds
+  // that to the ancestors once (a20-a25, src/spllt_factorization_mod.F90:39-261).  Here: maximal
+  // subtrees whose nodes all have one block column of at most one panel and whose modelled time on
+  // ONE CU stays within opt.subtree_us; one workgroup each, all in one launch beside the lowest
+  // levels of the rest of the tree.  What it buys: the leaves' updates -- thousands of tiles whose
+  // scatter-adds into far, cold ancestors bound the lowest levels -- land in the subtree's own
+  // block columns and in its generated element (a few hundred KB, cache-resident while the subtree
+  // is being worked on) instead, and the ancestors see one add per entry of the generated element.
+  // in_sub[s] = 1 for the nodes the tasks cover; sub_event = the event the launch records (-1: no
+  // task, or a single-stream program), sub_lstar = the lowest level an ancestor of a subtree root has.
+  // ---------------------------------------------------------------------------------------------
+  std::vector<char> in_sub;
+  int sub_event = -1, sub_lstar = INT_MAX;
+  void subtree_tasks(const std::vector<int64_t>& dinv_slot) {
+    const int nn = S.nnodes;
+    in_sub.assign((size_t)nn, 0);
+    const double budget = (double)env_int("SPLLT_SUBTREE_US", opt.subtree_us);
+    if (!env_int("SPLLT_SUBTREES", opt.subtrees ? 1 : 0) || budget <= 0) return;
+    for (int s = 0; s < nn; ++s)
+      if (S.sparent[s] <= s) return;                        // (children before parents, or no tasks)
+    // modelled time of a node inside a task (one CU): Cholesky of the panel, solve of the 64-row
+    // blocks below, one 64 x 64 tile of the update per pair of them
+    const double kInf = 1e30;
+    std::vector<double> cost((size_t)nn);
+    for (int s = 0; s < nn; ++s) {
+      const int w = S.ncol(s), m = S.nrow(s);
+      const bool ok = S.node_bcol0[s + 1] - S.node_bcol0[s] == 1 && w <= pw && w <= kPanelMax && m - w < 32768;
+      const double nrb = cdiv(m - w, 64);
+      cost[(size_t)s] = ok ? 12.0 + 2.0 * nrb + 2.5 * 0.5 * nrb * (nrb + 1) : kInf;
+    }
+    for (int s = 0; s < nn; ++s) {
+      const int p = S.sparent[s];
+      if (p < nn) cost[(size_t)p] = (cost[(size_t)p] < kInf && cost[(size_t)s] < kInf) ? cost[(size_t)p] + cost[(size_t)s] : kInf;
+    }
+    std::vector<int> root_of((size_t)nn, -1);
+    for (int s = nn - 1; s >= 0; --s) {
+      if (cost[(size_t)s] > budget) continue;
+      const int p = S.sparent[s];
+      root_of[(size_t)s] = (p < nn && root_of[(size_t)p] >= 0) ? root_of[(size_t)p] : s;
+    }
+    std::vector<int> roots;
+    for (int s = 0; s < nn; ++s)
+      if (root_of[(size_t)s] == s) roots.push_back(s);
+    if (roots.empty()) return;
+    // longest first: the launch ends with its longest task
+    std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    std::vector<std::vector<int>> members((size_t)nn);
+    for (int s = 0; s < nn; ++s)
+      if (root_of[(size_t)s] >= 0) {
+        members[(size_t)root_of[(size_t)s]].push_back(s);
+        in_sub[(size_t)s] = 1;
+      }
+    Launch L;
+    L.kind = L_SUBTREE;
+    L.level = 0;
+    L.first = (int64_t)P.sub_tasks.size();
+    L.tile = 64;
+    L.flops = 0;
+    auto push_unit = [&](UpdUnit u) {
+      u.a_w = S.bcols[u.src_bcol0].width;
+      u.a_off = S.bcols[u.src_bcol0].off;
+      P.units.push_back(u);
+      const double fl = 2.0 * u.a_w * ((double)u.M * u.N - 0.5 * u.N * (u.N - 1));
+      P.flops_between += fl;
+      L.flops += fl;
+    };
+    for (int r : roots) {
+      const int wr = S.ncol(r), mr = S.nrow(r);
+      const int* ridx = S.rows(r);
+      const int rend = S.sptr[r + 1] - 1;                   // the root's last column
+      SubTask T{};
+      T.node_first = (int)P.sub_nodes.size();
+      T.g_n = members[(size_t)r].size() > 1 ? mr - wr : 0;
+      T.g_off = P.gen_size;
+      P.gen_size += (int64_t)T.g_n * (T.g_n + 1) / 2;
+      if (S.sparent[r] < nn) sub_lstar = std::min(sub_lstar, S.level[S.sparent[r]]);
+      for (int s : members[(size_t)r]) {
+        const int b = S.node_bcol0[s];
+        const BlockCol& B = S.bcols[b];
+        const int w = S.ncol(s), m = S.nrow(s);
+        SubNode N{};
+        N.off = B.off;
+        N.dinv_off = dinv_slot[(size_t)b];
+        N.w = w;
+        N.nrow = m;
+        N.gcol = S.sptr[s];
+        N.unit_first = (int)P.units.size();
+        N.root = s == r ? 1 : 0;
+        std::vector<UpdUnit> us;
+        between_templates(s, us, s == r ? -1 : r);          // the root: all its ancestors; the others: up to the root
+        for (const UpdUnit& u : us) push_unit(u);
+        if (s != r && T.g_n > 0) {
+          // what leaves the subtree: the rows of s beyond the root's columns, against themselves
+          const int* idx = S.rows(s);
+          int cout = w;
+          while (cout < m && idx[cout] <= rend) cout++;
+          if (cout < m) {
+            const int64_t base = (int64_t)P.relpos.size();
+            int q = wr;
+            for (int i = cout; i < m; ++i) {
+              while (q < mr && ridx[q] < idx[i]) q++;
+              if (q >= mr || ridx[q] != idx[i]) {
+                std::fprintf(stderr, "spllt-hip: structure inclusion violated (node %d -> subtree root %d)\n", s, r);
+                q = std::min(q, mr - 1);
+              }
+              P.relpos.push_back(q - wr);
+            }
+            UpdUnit u{};
+            u.b_bcol0 = -1;
+            u.lower = 1;
+            u.mode = MODE_GEN;
+            u.d_off = T.g_off;
+            u.d_ld = 0;
+            u.relrow_off = base;
+            u.gcol_off = base;
+            u.src_bcol0 = b;
+            u.nseg = 1;
+            u.seg_r0 = 0;
+            u.seg_stride = nb;
+            u.src_r0 = cout;
+            u.src_c0 = cout;
+            u.M = m - cout;
+            u.N = m - cout;
+            u.k0 = 0;
+            u.klen = -1;
+            u.dinv_ld = -1;
+            push_unit(u);
+          }
+        }
+        N.unit_count = (int)P.units.size() - N.unit_first;
+        P.sub_nodes.push_back(N);
+        const double fp = (double)w * w * w / 3.0, ft = (double)(m - w) * w * w;
+        P.flops_potrf += fp;
+        P.flops_trsm += ft;
+        L.flops += fp + ft;
+      }
+      T.node_count = (int)P.sub_nodes.size() - T.node_first;
+      P.sub_tasks.push_back(T);
+    }
+    L.count = (int64_t)P.sub_tasks.size() - L.first;
+    L.stream = opt.lookahead ? ST_SIDE : ST_CHAIN;
+    if (opt.lookahead) {
+      sub_event = P.nevents++;
+      L.record = sub_event;
+    }
+    P.launches.push_back(L);
+  }
+
   void run() {
     P.pw = pw;
     // A block-column step whose block columns are wider than one panel runs in CHAIN BLOCKS of up
@@ -518,12 +669,15 @@ struct Builder {
     // ranks happens there), then the replicated top tree.
     const bool partitioned = opt.node_owner != nullptr && opt.nranks > 1;
     const int nphase = partitioned ? 2 : 1;
+    in_sub.assign((size_t)nn, 0);
+    if (!partitioned && !det_all && buffer_levels == 0) subtree_tasks(dinv_slot);
+    bool sub_waited = sub_event < 0;
     for (int ph = 0; ph < nphase; ++ph) {
     std::vector<std::vector<int>> by_level(maxlevel + 1);
     for (int s = 0; s < nn; ++s) {
       bool take = true;
       if (partitioned) take = (ph == 0) ? (opt.node_owner[s] == opt.rank) : (opt.node_owner[s] < 0);
-      if (take) by_level[S.level[s]].push_back(s);
+      if (take && !in_sub[(size_t)s]) by_level[S.level[s]].push_back(s);
     }
     dist2 = partitioned && ph == 1 && opt.top_owner != nullptr;
     // event of the extend-add that delivers the block columns of a top-tree level (distributed top
@@ -656,6 +810,16 @@ struct Builder {
       std::vector<std::vector<UpdUnit>> tmpl(nodes.size());
       std::vector<int> emitted(nodes.size(), 0);
       for (size_t i = 0; i < nodes.size(); ++i) between_templates(nodes[i], tmpl[i]);
+      if (!sub_waited && lev >= sub_lstar) {
+        // the first level that holds ancestors of subtree roots: everything from here on is behind
+        // the subtree tasks (this marker in the chain stream's order, the other streams through the
+        // chain's events); what runs below this level only shares atomic destinations with them
+        std::vector<UpdUnit> none;
+        Edge e = edge(ST_CHAIN);
+        e.wait0 = sub_event;
+        emit_gemm(lev, none, 0.0, true, e);
+        sub_waited = true;
+      }
       if (xpipe && xlev_event[(size_t)lev] >= 0) {
         // pipelined extend-add: the block columns of this top-tree level are here when their own
         // reduce-scatter is (every launch of the level is behind this marker: in the chain stream's
@@ -1159,6 +1323,16 @@ struct Builder {
       ev_level = P.nevents++;
       X.record = ev_level;
       P.launches.push_back(X);
+    }
+    if (!sub_waited) {
+      // nothing above the subtree tasks (they cover whole trees of the forest): the end waits for them
+      std::vector<UpdUnit> none;
+      Edge e = edge(ST_FAR);
+      e.wait0 = sub_event;
+      e.wait1 = ev_level;
+      ev_level = P.nevents++;
+      e.record = ev_level;
+      emit_gemm(maxlevel, none, 0.0, true, e);
     }
     P.final_event = ev_level;
   }

@@ -25,7 +25,12 @@ namespace spx {
 
 constexpr int kPanelMax = 64;  // widest diagonal panel the POTRF kernel accepts
 
-enum UnitMode : int { MODE_DIRECT = 0, MODE_SCATTER = 1, MODE_TRSM = 2, MODE_BUFFER = 3 };
+enum UnitMode : int { MODE_DIRECT = 0, MODE_SCATTER = 1, MODE_TRSM = 2, MODE_BUFFER = 3, MODE_GEN = 4 };
+// MODE_GEN (subtree tasks, L_SUBTREE): the part of a node's update that LEAVES its subtree is added
+// into the subtree's generated element -- the lower triangle, packed by rows, of the square matrix
+// over the rows below the subtree root's columns (d_off = its offset in the generated-element
+// scratch; row i of it starts at i (i + 1) / 2) -- at the positions relpos[relrow_off + i] (row)
+// and relpos[gcol_off + j] (column) of the root's row list.
 // MODE_BUFFER (deterministic engine): the product of an inter-node update unit is STORED, as a
 // dense M x N row-major block, in a scratch buffer (d_off = its offset there, d_ld = N); a
 // k_gather launch then subtracts the buffered blocks from their destination tiles in a fixed
@@ -108,6 +113,25 @@ struct PanelUnit {
 };
 static_assert(sizeof(PanelUnit) == 48, "PanelUnit layout (mirrored in spllt_amd/api.py)");
 
+// A small subtree as one device task (L_SUBTREE): nodes [node_first, node_first + node_count) of
+// sub_nodes, children before parents, the last one is the subtree's root.
+struct SubTask {
+  int64_t g_off;     // offset of the generated element in the scratch (packed lower triangle)
+  int node_first, node_count;
+  int g_n;           // its order = rows below the root's columns (0: a single node, nothing to collect)
+  int pad_;
+};
+static_assert(sizeof(SubTask) == 24, "SubTask layout (mirrored in spllt_amd/api.py)");
+struct SubNode {
+  int64_t off;       // arena offset of the node's block column (it has one, <= one panel wide)
+  int64_t dinv_off;  // where the inverse of its diagonal block goes
+  int w, nrow;       // columns, rows
+  int gcol;          // pivot position of column 0 (error reporting)
+  int unit_first, unit_count;   // its update units (units[]: MODE_SCATTER / MODE_GEN, K = all w columns)
+  int root;          // 1: the subtree's root -- its units add the generated element to what they scatter
+};
+static_assert(sizeof(SubNode) == 40, "SubNode layout (mirrored in spllt_amd/api.py)");
+
 // Deterministic assembly (k_gather): one workgroup per destination tile (<= 64 x 64 entries of
 // a block column) walks its items in order; an item is the part of one buffered update block
 // (MODE_BUFFER unit) that lands in the tile.
@@ -134,7 +158,14 @@ struct GatherTile {
 static_assert(sizeof(GatherTile) == 48, "GatherTile layout (mirrored in spllt_amd/api.py)");
 
 enum LaunchKind : int { L_POTRF = 0, L_GEMM = 1, L_EXCHANGE = 2, L_CHAIN = 4, /* 5: removed */ L_GATHER = 6,
-                        L_PANEL = 7, L_CHAIN4 = 8, L_TRSM4 = 9 };
+                        L_PANEL = 7, L_CHAIN4 = 8, L_TRSM4 = 9, L_SUBTREE = 10 };
+// L_SUBTREE (k_subtree): one workgroup per SubTask factorizes a whole small subtree, node by node in
+// post-order -- the reference's subtree task (a20-a25: spllt_subtree_factorize,
+// src/spllt_factorization_mod.F90:196-261, kernels_mod:780-821): Cholesky of the node's (one-panel)
+// block column, solve of its rows, then its update units: into the nodes of the subtree directly
+// (MODE_SCATTER units), into the subtree's generated element what leaves it (MODE_GEN); the root's
+// units carry the generated element with them into the ancestors (ONE extend-add per subtree,
+// factorization_mod:39-191).
 // L_CHAIN4 (k_chain_block): one workgroup factors the whole diagonal block of a CHAIN BLOCK of up to
 // four panels (ChainUnit with pn = its width <= 4 pw) and emits the panels' inverses (per panel, the
 // layout of the one-panel chain steps).
@@ -210,6 +241,10 @@ struct Program {
   std::vector<PotrfUnit> potrf_units;  // L_POTRF (operator twins only: inverse of given factors)
   std::vector<ChainUnit> chain_units;  // L_CHAIN
   std::vector<PanelUnit> panel_units;  // L_PANEL (tiles: unit, ti)
+  std::vector<SubTask> sub_tasks;      // L_SUBTREE
+  std::vector<SubNode> sub_nodes;
+  int64_t gen_size = 0;                // doubles of the generated-element scratch (zero between factorizations:
+                                       // the root's units clear what they read)
   std::vector<GatherItem> gather_items;
   std::vector<GatherTile> gather_tiles;  // L_GATHER
   int64_t scratch_size = 0;     // doubles of the MODE_BUFFER scratch (largest launch)
@@ -266,6 +301,12 @@ struct ScheduleOptions {
   int tile128_min = 4096;     // launches of up to this many 64-tiles keep 64-tiles (the 128-tile pays when a
                               // launch fills the chip for several rounds; throughput-bound problems: 1024)
   bool pair_sources = true;   // trailing updates inside a node by two source block columns at a time
+  bool subtrees = false;      // small subtrees (every node one panel wide at most, modelled time within
+  int subtree_us = 300;       // subtree_us) run as ONE workgroup each (L_SUBTREE) instead of level by level;
+                              // single-GPU, non-deterministic programs only.  Off (SPLLT_SUBTREES=1, engine flag
+                              // bit 18): measured slower at every budget and size (profiles/r04/subtree_tasks_ab.txt)
+                              // -- a task walks its nodes one after the other on one CU, the level-batched
+                              // launches spread the nodes of a level, and the tiles of a node, over the chip
   bool deterministic = false; // no atomics: inter-node updates through a buffer + ordered gather
                               // (MODE_BUFFER / k_gather); implies no zones, no early slices
   int buffer_levels = 0;      // the inter-node updates of the tree levels below this one go through the

@@ -49,6 +49,7 @@ def emulate_program(f, val, exchange=None, partitioned=False):
         return out
 
     bc_nrow = f.sym("bcol_nrow")
+    gen = None                                               # generated elements of the subtree tasks
     for kind, level, first, count, tile in launches[:, :5]:
         if kind == 2:  # EXCHANGE k: pack, the caller's collective, unpack (engine.cpp pre_/post_exchange)
             xk, xfirst, xn, xelems, xchunk = (int(v) for v in f.program("exchanges")[first])
@@ -65,6 +66,49 @@ def emulate_program(f, val, exchange=None, partitioned=False):
                 if (xk == 2 and root == rank) or (xk == 1 and root != rank):
                     continue
                 (dinv if space else arena)[off:off + cnt] = xbuf[xo:xo + cnt]
+            continue
+        if kind == 10:  # one small subtree per workgroup (k_subtree): nodes in post-order
+            tasks, snodes = f.program("sub_tasks"), f.program("sub_nodes")
+            if gen is None:
+                gen = np.zeros(max(1, f.program("gen_size")))
+            for t in tasks[first:first + count]:
+                for nd in snodes[int(t["node_first"]):int(t["node_first"]) + int(t["node_count"])]:
+                    w, m, off = int(nd["w"]), int(nd["nrow"]), int(nd["off"])
+                    blk = arena[off:off + m * w].reshape(m, w)          # (view: a node has ONE block column)
+                    dd = np.tril(blk[:w])
+                    Lb = sl.cholesky(dd + np.tril(dd, -1).T, lower=True)
+                    blk[:w][np.tril_indices(w)] = Lb[np.tril_indices(w)]
+                    inv = sl.solve_triangular(Lb, np.eye(w), lower=True)
+                    do = int(nd["dinv_off"])
+                    dinv[do:do + w * w] = inv.ravel()
+                    blk[w:] = blk[w:] @ inv.T
+                    for u in units[int(nd["unit_first"]):int(nd["unit_first"]) + int(nd["unit_count"])]:
+                        assert u["nseg"] == 1 and u["klen"] < 0 and u["lower"] and u["src_r0"] == u["src_c0"]
+                        r0, M, N = int(u["src_r0"]), int(u["M"]), int(u["N"])
+                        P = blk[r0:r0 + M] @ blk[r0:r0 + N].T
+                        ii, jj = np.arange(M)[:, None], np.arange(N)[None, :]
+                        keep = ii >= jj
+                        if u["mode"] == 4:       # MODE_GEN: into the subtree's generated element
+                            assert not nd["root"] and u["d_off"] == t["g_off"] and u["relrow_off"] == u["gcol_off"]
+                            gr = relpos[int(u["relrow_off"]) + ii]
+                            gc = relpos[int(u["gcol_off"]) + jj]
+                            assert (gr < t["g_n"]).all() and (gr >= 0).all() and (np.diff(gr[:, 0]) > 0).all()
+                            idx = int(u["d_off"]) + gr * (gr + 1) // 2 + gc
+                            np.subtract.at(gen, idx[keep], P[keep])
+                            continue
+                        assert u["mode"] == MODE_SCATTER
+                        dr = relpos[int(u["relrow_off"]) + ii] - int(u["d_row0"])
+                        dc = rlist[int(u["gcol_off"]) + jj] - int(u["d_col0"])
+                        assert (dr >= 0).all() and (dc >= 0).all() and (dc < u["d_ld"]).all()
+                        if nd["root"] and t["g_n"] > 0:
+                            gi, gj = r0 - w + ii, r0 - w + jj
+                            gidx = int(t["g_off"]) + gi * (gi + 1) // 2 + gj
+                            P = P.copy()
+                            P[keep] -= gen[gidx[keep]]
+                            gen[gidx[keep]] = 0.0
+                        idx = int(u["d_off"]) + dr * int(u["d_ld"]) + dc
+                        np.subtract.at(arena, idx[keep], P[keep])
+            assert not gen.any(), "the generated elements are zero again when the launch ends"
             continue
         if kind == 4:  # one step of the panel chain per unit (k_chain_panel)
             for q in f.program("chains")[first:first + count]:

@@ -29,6 +29,10 @@ def test_fuzz_factor_and_solve(seed, monkeypatch):
     # widths that are no multiple of 4, block columns of 1-40 panels), the graph replays and eager launches in turn
     monkeypatch.setenv("SPLLT_CHAIN4", "1" if seed % 3 == 2 else "0")
     monkeypatch.setenv("SPLLT_HIP_GRAPH", str(seed % 4 - 1) if seed % 4 else "-1")
+    # every other case with the small subtrees as single device tasks (k_subtree), at budgets that make
+    # tasks of one node, of a few, and of whole trees
+    monkeypatch.setenv("SPLLT_SUBTREES", str(seed // 2 % 2))
+    monkeypatch.setenv("SPLLT_SUBTREE_US", str([40, 300, 5000][seed % 3]))
     kind = seed % 4
     if kind == 0:
         A = matgen.nd_like(tuple(int(x) for x in rng.integers(4, 11, size=3)), int(rng.integers(1, 3)))

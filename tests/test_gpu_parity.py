@@ -660,6 +660,44 @@ def test_engine_variants_match_oracle(flags, cb):
     assert bwd_err(A, f.solve(b), b) <= 1e-14
 
 
+@pytest.mark.parametrize("graph", [0, 1, 2])
+@pytest.mark.parametrize("budget", [40, 300, 100000])
+@pytest.mark.parametrize("gen,nb,pw,nemin", [(lambda: matgen.poisson2d(64), 64, None, 8),        # deep subtrees of tiny nodes
+                                             (lambda: matgen.poisson2d(12), 64, None, 4),        # the whole tree in one task
+                                             (lambda: matgen.nd_like((12, 11, 10), 2), 64, None, 16),
+                                             (lambda: matgen.fe27((8, 7, 6), 3), 48, 24, 8),     # ragged panels of 24
+                                             (lambda: matgen.poisson3d(14), 256, None, 32)])
+def test_subtree_tasks_match_oracle(gen, nb, pw, nemin, budget, graph, monkeypatch):
+    """k_subtree (L_SUBTREE; opt-in): a whole small subtree per workgroup -- Cholesky, solve and update
+    units of its nodes in post-order, what leaves the subtree through the generated-element scratch,
+    one extend-add from the root (the reference's a20-a25: src/spllt_factorization_mod.F90:39-261).
+    Against the oracle; over new values on the same pattern (the scratch is zero again after every
+    factorization -- also after one that failed); eager and as a graph node."""
+    monkeypatch.setenv("SPLLT_SUBTREES", "1")
+    monkeypatch.setenv("SPLLT_SUBTREE_US", str(budget))
+    monkeypatch.setenv("SPLLT_HIP_GRAPH", str(graph))
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw)
+    L = f.program("launches")
+    assert (L[:, 0] == 10).sum() == 1 and len(f.program("sub_tasks")) == L[0, 3] > 0
+    for scale in (1.0, 2.5):
+        got = f.factor(val * scale).wait().get_factor()
+        o, rc = oracle_factor(f, val * scale)
+        assert rc == 0
+        assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = (A * 2.5) @ np.ones(f.n)
+    assert bwd_err(A * 2.5, f.solve(b), b) <= 1e-14
+    bad = val.copy()
+    bad[0] = -1.0                                   # not positive definite: reported, and the next one is clean
+    with pytest.raises(api.SplltError) as ei:
+        f.factor(bad).wait()
+    assert ei.value.flag == -20
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val)
+    assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    f.close()
+
+
 @pytest.mark.parametrize("flags", [32768, 65536, 65536 | 4096, 32768 | 512, 65536 | 2048])
 def test_graph_replay_matches_oracle(flags):
     """SURVEY 8(f) row f1, analyse once / factorize many (reference kernels_mod:2301-2364): the
@@ -693,6 +731,7 @@ def test_fused_panel_launches_larger_than_the_chip(gen, nb, monkeypatch):
     early ones have finished - they must still find the blocks unsolved.  The default only fuses
     launches of <= 64 workgroups; here every step is fused."""
     monkeypatch.setenv("SPLLT_FUSED_PANEL_MAX", "1000000")
+    monkeypatch.setenv("SPLLT_SUBTREES", "0")      # (the leaves stay in the level-batched launches)
     A = gen()
     f, val = make_case(A, nb=nb, nemin=32)
     L = f.program("launches")
@@ -1029,6 +1068,7 @@ def test_dma_update_kernel_on_every_large_launch(gen, nb, pw, flags, monkeypatch
     deterministic (BUFFER epilogue) engines."""
     monkeypatch.setenv("SPLLT_TILE_SMALL", "0")
     monkeypatch.setenv("SPLLT_TILE_TINY", "0")
+    monkeypatch.setenv("SPLLT_SUBTREES", "0")      # (the leaves' updates stay 128-tile launches)
     A = gen()
     f, val = make_case(A, nb=nb, nemin=16, panel_width=pw, engine_flags=flags)
     L = f.program("launches")

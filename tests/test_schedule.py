@@ -150,6 +150,21 @@ def _access_sets(f):
                 W.append((b, c0, c0 + cw, c0, c0 + cw))
                 for p in range(c0 // pw, (c0 + cw - 1) // pw + 1):
                     W.append(("wi", b, p))
+        elif kind == 10:
+            # subtree tasks: a task owns the block columns of its nodes (read + written by it alone) and
+            # its generated element; what its root sends up lands in the ancestors with atomics
+            snodes = f.program("sub_nodes")
+            for t in f.program("sub_tasks")[first:first + count]:
+                W.append(("gen", int(t["g_off"]), 0))
+                for nd in snodes[int(t["node_first"]):int(t["node_first"]) + int(t["node_count"])]:
+                    b = bcol_of(nd["off"])
+                    assert int(bw[b]) == nd["w"] and int(bnr[b]) == nd["nrow"]
+                    W.append((b, 0, int(bnr[b]), 0, int(bw[b])))
+                    W.append(("wi", b, 0))
+                    for u in units[int(nd["unit_first"]):int(nd["unit_first"]) + int(nd["unit_count"])]:
+                        if u["mode"] == 1 and nd["root"]:
+                            db = bcol_of(u["d_off"])
+                            At.append((db, 0, int(bnr[db]), 0, int(bw[db])))
         elif kind == 2:
             # exchange: the pack reads, the unpack overwrites whole block columns (engine.cpp
             # pre_exchange / post_exchange)
@@ -328,7 +343,7 @@ def _stream_dag_orders_every_conflict(gen, nb, pw, cb, flags, chain4, monkeypatc
     bad, launches, before, rec_at, last_in_stream = dag_violations(f)
     assert not bad, bad[:3]
     assert (launches[:, 6] == 1).any(), "expected bulk-stream launches in this case"
-    assert not (launches[:, 6] == 3).any(), "the side stream is not used"
+    assert ((launches[:, 6] == 3) == (launches[:, 0] == 10)).all(), "the side stream carries the subtree tasks only"
     kinds = launches[:, 0]
     if chain4 and nb > pw:       # block columns of several panels: chain blocks + their row solves
         assert (kinds == 8).any() and (kinds == 9).any()
@@ -411,3 +426,82 @@ def test_inter_node_updates_are_sliced_over_the_far_stream(flags):
     assert len(far_events & chain_waits) >= 3
     got = emulate_program(f, val)
     assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+_SUB_CASES = {"p2d-40": (lambda: matgen.poisson2d(40), 64, 64, 8),        # deep subtrees of tiny nodes
+              "p2d-12": (lambda: matgen.poisson2d(12), 64, 64, 4),        # the whole tree fits one task
+              "nd-32-16": (lambda: matgen.nd_like((9, 8, 8), 2), 32, 16, 8),
+              "p3d-24-8": (lambda: matgen.poisson3d(9), 24, 8, 8)}
+
+
+@pytest.mark.parametrize("flags", [0, 2, 64, 512])
+@pytest.mark.parametrize("budget", [40, 300, 100000])
+@pytest.mark.parametrize("case", sorted(_SUB_CASES))
+def test_subtree_tasks_program(case, budget, flags, monkeypatch):
+    """Small subtrees as single device tasks (L_SUBTREE, the reference's a20-a25 shape; opt-in): every
+    node belongs to a task or to the level-batched program, never both; a task holds a whole subtree
+    (children before parents, the root last); what leaves the subtree from below the root goes through
+    the task's generated element (MODE_GEN) and the root takes it to the ancestors; the stream DAG
+    orders the tasks (side stream) against everything that touches their block columns or their
+    ancestors non-atomically; the interpreted program reproduces the dense factor."""
+    monkeypatch.setenv("SPLLT_SUBTREES", "1")
+    monkeypatch.setenv("SPLLT_SUBTREE_US", str(budget))
+    gen, nb, pw, nemin = _SUB_CASES[case]
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=nemin, panel_width=pw, engine_flags=flags)
+    L = f.program("launches")
+    tasks, snodes, units = f.program("sub_tasks"), f.program("sub_nodes"), f.program("units")
+    assert (L[:, 0] == 10).sum() == 1 and L[0, 0] == 10 and L[0, 3] == len(tasks) > 0
+    assert L[0, 6] == (0 if flags & 2 else 3)            # side stream of the multi-stream program
+    off, sparent = f.sym("bcol_off"), f.sym("sparent")
+    node_bc0, bc_node = f.sym("node_bcol0"), f.sym("bcol_node")
+    in_task = {}
+    for ti, t in enumerate(tasks):
+        nd = snodes[int(t["node_first"]):int(t["node_first"]) + int(t["node_count"])]
+        ids = [int(bc_node[int(np.searchsorted(off, q["off"]))]) for q in nd]
+        assert ids == sorted(ids) and nd[-1]["root"] == 1 and not nd[:-1]["root"].any()
+        for s in ids:
+            assert s not in in_task and node_bc0[s + 1] - node_bc0[s] == 1
+            in_task[s] = ti
+        root = ids[-1]
+        for s in ids[:-1]:                                 # a whole subtree: every parent chain ends in the root
+            a = s
+            while a != root:
+                a = int(sparent[a])
+                assert a in ids
+        kids = [c for c in range(len(sparent)) if int(sparent[c]) in ids]
+        assert all(c in ids for c in kids), "a task holds all descendants of its root"
+        gen_units = 0
+        for q in nd:
+            us = units[int(q["unit_first"]):int(q["unit_first"]) + int(q["unit_count"])]
+            gen_units += int((us["mode"] == 4).sum())
+            assert not (q["root"] and (us["mode"] == 4).any())
+        below_root = int(nd[-1]["nrow"]) - int(nd[-1]["w"])      # (0: the root of a tree of the forest)
+        assert t["g_n"] == (below_root if len(ids) > 1 else 0) and (gen_units > 0) <= (t["g_n"] > 0)
+    # nothing of a task's nodes appears in the level-batched part
+    tiles = f.program("tiles")
+    for kind, level, first, count, tile in L[1:, :5]:
+        if kind == 1 and count > 0:
+            for uid in set(tiles[first:first + count]["unit"].tolist()):
+                assert int(bc_node[int(units[uid]["src_bcol0"])]) not in in_task
+    if budget == 100000 and case == "p2d-12":
+        assert len(in_task) == f.sym_info()["nnodes"], "the whole forest in tasks: the program ends behind them"
+    if not flags & 2:
+        bad, launches, before, rec_at, last_in_stream = dag_violations(f)
+        assert not bad, bad[:3]
+        fin = max(rec_at.values())
+        for st, i in last_in_stream.items():
+            assert i == fin or (before[fin] >> i & 1) or st == launches[fin, 6]
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
+
+
+def test_subtree_tasks_are_opt_in(monkeypatch):
+    monkeypatch.delenv("SPLLT_SUBTREES", raising=False)
+    f, val = make_case(matgen.poisson2d(40), nb=64, nemin=8)
+    assert not (f.program("launches")[:, 0] == 10).any() and f.program("gen_size") == 0
+    f2, _ = make_case(matgen.poisson2d(40), nb=64, nemin=8, engine_flags=262144)     # bit 18
+    assert (f2.program("launches")[:, 0] == 10).any() and f2.program("gen_size") > 0
+    for fl in (4096, 262144 | 4096):                                                  # never in the deterministic engine
+        f3, _ = make_case(matgen.poisson2d(40), nb=64, nemin=8, engine_flags=fl)
+        assert not (f3.program("launches")[:, 0] == 10).any()
