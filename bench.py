@@ -422,6 +422,33 @@ def main():
         except Exception as e:   # noqa: BLE001 - a reference point, never a reason to lose the line
             dgemm_ref = {"error": repr(e)[:200]}
     extra, small = [], []
+    # Throughput of a STREAM of factorizations of one pattern (a time-stepping caller: analyse once,
+    # factorize many): two handles on the same pattern, the next factorization submitted while the
+    # previous one is in its latency-bound top levels.  Reported beside `value`, never as `value`
+    # (the metric is one factorization at a time, like the reference's driver).
+    two_handles = None
+    if not args.no_extra_configs:
+        try:
+            f2 = api.Factorization(n, ptr, row, nb=nb, nemin=args.nemin, prune_tree=False, order=order,
+                                   panel_width=args.panel, engine_flags=int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")))
+            f2.factor_dev(dval.data_ptr()).wait()
+            f.factor_dev(dval.data_ptr()).wait()
+            torch.cuda.synchronize()
+            reps = max(2, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f.factor_dev(dval.data_ptr())
+                f2.factor_dev(dval.data_ptr())
+                f.wait()
+                f2.wait()
+            torch.cuda.synchronize()
+            t2 = (time.perf_counter() - t0) / (2 * reps)
+            two_handles = {"ms_per_factorization": round(t2 * 1e3, 3), "gflops": round(flops / t2 / 1e9, 1),
+                           "note": "two handles of the same pattern in flight; informational, not the metric"}
+            f2.close()
+            del f2
+        except Exception as e:   # noqa: BLE001 - a diagnostic, never a reason to lose the line
+            two_handles = {"error": repr(e)[:200]}
     if not args.no_extra_configs and not args.mm and not args.rb and args.scale == 1.0:
         f.close()
         del dval
@@ -454,7 +481,8 @@ def main():
                    "device_solve_s": None if t_solve is None else round(t_solve, 5),
                    "launches": nlaunch, "kernel_table": table, "timeline": level_done, "check": check,
                    "engine_flags": int(os.environ.get("SPLLT_ENGINE_FLAGS", "0")), "nemin": args.nemin,
-                   "dgemm_reference": dgemm_ref, "configs": extra, "small_configs": small},
+                   "dgemm_reference": dgemm_ref, "two_handles_in_flight": two_handles, "configs": extra,
+                   "small_configs": small},
     }
     print(json.dumps(out))
 
