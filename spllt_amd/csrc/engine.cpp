@@ -1407,6 +1407,10 @@ int Engine::prepare_solve() {
     HIPCHK(tab.commit(&d_solve_tables_, [this](void** q, size_t b) { return dalloc(q, b); }), "upload solve tables");
   }
   HIPCHK(dalloc((void**)&d_y_, sizeof(double) * 4 * (size_t)std::max(1, S.n)), "hipMalloc(y)");
+  {
+    const char* e = std::getenv("SPLLT_SOLVE_DIAG4");
+    solve_four_ = prog_.pw == 64 && prog_.cb == 64 && !(e && std::atoi(e) == 0);
+  }
   solve_ready_ = true;
   return 0;
 }
@@ -1427,9 +1431,14 @@ int Engine::solve_dev(double* y_dev, int nrhs, int job, int phase) {
     const int cur = left >= 4 ? 4 : (left >= 2 ? 2 : 1);   // kernel variants: 4, 2 or 1 per sweep
     double* y = y_dev + (int64_t)done * n;
     auto run = [&](const std::vector<SolveLaunch>& ls, size_t a, size_t b) {
-      for (size_t i = a; i < b; ++i)
+      for (size_t i = a; i < b; ++i) {
+        // block columns of at most four 64-wide panels: the diagonal kernel that reads L in one round trip
+        bool four = solve_four_ && (ls[i].kind == SV_DIAG_FWD || ls[i].kind == SV_DIAG_BWD);
+        for (int64_t q = ls[i].first; four && q < ls[i].first + ls[i].count; ++q)
+          four = sprog_.units[(size_t)sprog_.diag_list[(size_t)q]].w <= 256;
         launch_solve(stream_, ls[i].kind, d_slist_, d_stiles_, ls[i].first, ls[i].count, d_sunits_, d_L_,
-                     d_dinv_, d_rlist_, y, cur, (int64_t)n);
+                     d_dinv_, d_rlist_, y, cur, (int64_t)n, four);
+      }
     };
     const size_t nf = sprog_.fwd.size(), nb = sprog_.bwd.size();
     if (do_fwd && (phase == -1 || phase == 0)) run(sprog_.fwd, 0, sprog_.fwd_nsub);

@@ -235,6 +235,7 @@ class Engine {
   SubTask* d_sub_tasks_ = nullptr;   // L_SUBTREE: one workgroup per small subtree
   SubNode* d_sub_nodes_ = nullptr;
   double* d_gen_ = nullptr;          // generated elements of the subtree tasks (zero between factorizations)
+  bool solve_four_ = false;        // the solve may use k_solve_diag4 (panels of 64)
   int* d_panel_cnt_ = nullptr;     // two "last reader" counters per panel unit (zero between launches)
   GatherTile* d_gtiles_ = nullptr;
   GatherItem* d_gitems_ = nullptr;

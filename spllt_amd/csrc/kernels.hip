@@ -2394,6 +2394,194 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
   }
 }
 
+// The same for block columns of at most four 64-wide panels (pw = cb = 64, w <= 256: the bench
+// configuration's nb = 256) with ONE round trip to memory: the panel steps are a dependent sequence,
+// but what they read of L does not depend on them -- every thread requests its share of the whole
+// strictly lower part of the diagonal block (96 values) when the kernel starts, and the inverse of the
+// next panel while it works on the current one, so a step is LDS reads, FMAs, a 16-lane reduction and
+// barriers.  (The general kernel above pays a global round trip per panel step: 24.6 us per 256-wide
+// block column forward, 14.1 backward, on the bench workload; 238 dependent launches per solve.)
+template <bool BWD, int NR>
+__global__ __launch_bounds__(256) void k_solve_diag4(const int* __restrict__ list,
+                                                     const SolveUnit* __restrict__ units,
+                                                     const double* __restrict__ L,
+                                                     const double* __restrict__ dinv,
+                                                     const int* __restrict__ rlist,
+                                                     double* __restrict__ y, int64_t ldy) {
+  __shared__ double xb[NR * 256];
+  __shared__ double tb[NR * 64];
+  __shared__ double part[4][NR * 64];
+  const SolveUnit u = units[list[blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 15, rr = tid >> 4;   // forward: 16 lanes per row, 16 rows per pass
+  const int w = u.w;
+  const int np = (w + 63) >> 6;
+  const double* A = L + u.off;
+  const int* idx = rlist + u.idx_off;
+  // ---- everything of L the steps will read ------------------------------------------------
+  double lv[3][4][12];       // forward: panel p + 1, row rr + 16 r, columns sub + 16 e (e < 4 (p + 1))
+  double bv[3][48];          // backward: panel p, column lane, rows 64 (p + 1) + wave + 4 i (i < 16 (3 - p))
+  if (!BWD) {
+#pragma unroll
+    for (int p = 1; p < 4; ++p) {
+      if (p >= np) break;
+      const int c0 = 64 * p, pn = min(64, w - c0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* row = A + (int64_t)(c0 + min(rr + 16 * r, pn - 1)) * w;
+#pragma unroll
+        for (int e = 0; e < 4 * p; ++e) lv[p - 1][r][e] = row[sub + 16 * e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      if (p + 1 >= np) break;
+      const int cj = 64 * p + lane;               // (a full panel: p + 1 < np)
+#pragma unroll
+      for (int i = 0; i < 16 * (3 - p); ++i) {
+        const int k = 64 * (p + 1) + wave + 4 * i;
+        bv[p][i] = A[(int64_t)min(k, w - 1) * w + cj];
+      }
+    }
+  }
+  // inverse of a panel: slot of panel p = dinv_off + sum of the squares of the panels before it (all 64 wide)
+  auto wload = [&](int p, double (&dv)[16]) {
+    const int pn = min(64, w - 64 * p);
+    const double* D = dinv + u.dinv_off + (int64_t)p * 4096;
+    if (!BWD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[4 * r + e] = D[(int64_t)min(rr + 16 * r, pn - 1) * pn + min(sub + 16 * e, pn - 1)];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dv[e] = D[(int64_t)min(wave + 4 * e, pn - 1) * pn + min(lane, pn - 1)];
+    }
+  };
+  double dv[16], dvn[16];
+  wload(BWD ? np - 1 : 0, dv);
+  for (int j = tid; j < w; j += 256) {
+    const int gi = idx[j];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) xb[q * 256 + j] = y[q * ldy + gi];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    if (pp >= np) break;
+    const int p = BWD ? np - 1 - pp : pp;
+    const int c0 = 64 * p, pn = min(64, w - c0);
+    if (pp + 1 < np) wload(BWD ? p - 1 : p + 1, dvn);
+    if (!BWD) {
+      // t_j = y_j - sum_{k < c0} L[c0 + j][k] x_k
+      if (pp > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            double sa = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4 * pp; ++e) sa = __builtin_fma(lv[pp - 1][r][e], xb[q * 256 + sub + 16 * e], sa);
+            sa = sum16(sa);
+            const int j = rr + 16 * r;
+            if (sub == 0 && j < pn) tb[q * 64 + j] = xb[q * 256 + c0 + j] - sa;
+          }
+      } else if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) tb[q * 64 + tid] = xb[q * 256 + tid];
+      }
+      __syncthreads();
+      // x_j = sum_{k <= j} Dinv[j][k] t_k
+      double acc[4][NR];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          double sa = 0.0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = sub + 16 * e;
+            sa = __builtin_fma(k < pn ? dv[4 * r + e] : 0.0, tb[q * 64 + min(k, pn - 1)], sa);
+          }
+          acc[r][q] = sum16(sa);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = rr + 16 * r;
+        if (sub == 0 && j < pn) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) xb[q * 256 + c0 + j] = acc[r][q];
+        }
+      }
+      __syncthreads();
+    } else {
+      // t_j = y_j - sum_{k >= c0 + pn} L[k][c0 + j] x_k : lane = column j, the waves split k
+      if (pp > 0) {
+        double sa[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) sa[q] = 0.0;
+        // (p = np - 1 - pp: the rows below are those of the pp panels behind it; bv[p] was loaded for
+        // i < 16 (3 - p), of which the first 16 pp exist)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          if (pc != p) continue;
+#pragma unroll
+          for (int i = 0; i < 16 * (3 - pc); ++i) {
+            const int k = 64 * (pc + 1) + wave + 4 * i;
+            const double a = k < w ? bv[pc][i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, xb[q * 256 + min(k, w - 1)], sa[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) part[wave][q * 64 + lane] = sa[q];
+        __syncthreads();
+        if (tid < pn) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q)
+            tb[q * 64 + tid] = xb[q * 256 + c0 + tid] - (part[0][q * 64 + tid] + part[1][q * 64 + tid] +
+                                                         part[2][q * 64 + tid] + part[3][q * 64 + tid]);
+        }
+      } else if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) tb[q * 64 + tid] = xb[q * 256 + c0 + tid];
+      }
+      __syncthreads();
+      // x_j = sum_{k >= j} Dinv[k][j] t_k
+      {
+        double sa[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) sa[q] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int k = wave + 4 * e;
+          const double a = k < pn ? dv[e] : 0.0;
+#pragma unroll
+          for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, tb[q * 64 + min(k, pn - 1)], sa[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) part[wave][q * 64 + lane] = sa[q];
+      }
+      __syncthreads();
+      if (tid < pn) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+          xb[q * 256 + c0 + tid] = part[0][q * 64 + tid] + part[1][q * 64 + tid] +
+                                   part[2][q * 64 + tid] + part[3][q * 64 + tid];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dv[e] = dvn[e];
+  }
+  for (int j = tid; j < w; j += 256) {
+    const int gi = idx[j];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) y[q * ldy + gi] = xb[q * 256 + j];
+  }
+}
+
 // Rows below the diagonal tile, one strip of kSolveStripRows (64) rows per workgroup.
 //   forward : y[idx[r]] -= sum_k L[r][k] x_k      (x = solved entries of this block column)
 //   backward: y[idx[k]] -= sum_r L[r][k] x[idx[r]]
@@ -2467,14 +2655,20 @@ __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__
 template <int NR>
 static void launch_solve_nr(hipStream_t st, int kind, const int* list, const UpdTile* tiles,
                             int64_t first, int64_t count, const SolveUnit* units, const double* L,
-                            const double* dinv, const int* rlist, double* y, int64_t ldy) {
+                            const double* dinv, const int* rlist, double* y, int64_t ldy, bool four) {
   const dim3 g((unsigned)count), b(256);
   switch (kind) {
     case SV_DIAG_FWD:
-      hipLaunchKernelGGL((k_solve_diag<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+      if (four)
+        hipLaunchKernelGGL((k_solve_diag4<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+      else
+        hipLaunchKernelGGL((k_solve_diag<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
       break;
     case SV_DIAG_BWD:
-      hipLaunchKernelGGL((k_solve_diag<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+      if (four)
+        hipLaunchKernelGGL((k_solve_diag4<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+      else
+        hipLaunchKernelGGL((k_solve_diag<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
       break;
     case SV_STRIP_FWD:
       hipLaunchKernelGGL((k_solve_strip<false, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy);
@@ -2488,14 +2682,14 @@ static void launch_solve_nr(hipStream_t st, int kind, const int* list, const Upd
 // nr = 1, 2 or 4 right-hand sides per sweep: y[q * ldy + i]
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y, int nr, int64_t ldy) {
+                  const int* rlist, double* y, int nr, int64_t ldy, bool four) {
   if (count <= 0) return;
   if (nr >= 4)
-    launch_solve_nr<4>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
+    launch_solve_nr<4>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
   else if (nr >= 2)
-    launch_solve_nr<2>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
+    launch_solve_nr<2>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
   else
-    launch_solve_nr<1>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy);
+    launch_solve_nr<1>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
 }
 
 // ---------------------------------------------------------------------------

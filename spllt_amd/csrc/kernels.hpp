@@ -75,10 +75,11 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
                           const int* rdest_index, int d_m, const int* cdest_index, int d_n,
                           double* dest, int ldd);
 
-// one launch of the device solve (kind = SolveKind)
+// one launch of the device solve (kind = SolveKind); four: every block column of a DIAG launch has at
+// most four 64-wide panels (pw = cb = 64, w <= 256) -- the kernel that reads L in one round trip
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y, int nr, int64_t ldy);
+                  const int* rlist, double* y, int nr, int64_t ldy, bool four = false);
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
                           const int* col_list, int cls, int ndiag, const double* buffer);
 
