@@ -167,7 +167,10 @@ def run_extra_config(cfg_name, steps=2):
            "resid_2norm_rel": float(np.linalg.norm(r) / np.linalg.norm(b)),
            "bwd_err": float(np.linalg.norm(r) / (np.linalg.norm(b) + abs(A).max() * np.linalg.norm(x))),
            "dominant_kernel": roof["kernel"], "dominant_tflops": roof["achieved"],
-           "dominant_frac": roof["frac"], "dominant_frac_alone": roof["frac_alone"]}
+           "dominant_frac": roof["frac"], "dominant_frac_alone": roof["frac_alone"],
+           # the whole step against the same peak (the in-program figure of a kernel that runs on two
+           # streams at once counts the time of BOTH launches: it reads low while the chip is full)
+           "step_frac": round(flops / t / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
     f.close()
     del dval
     torch.cuda.empty_cache()
@@ -337,6 +340,7 @@ def main():
 
     roof, table, ms = roofline_from_profile(f, val)
     attach_pmc(roof, name)
+    roof["step_frac"] = round(value / 1e3 / FP64_MFMA_PEAK_TFLOPS, 4)     # the whole step against the same peak
     # the real program on the clock (spllt_hip_timeline: its own events, nothing added to the
     # streams): ms after the value scatter at which the last event of each tree level completed
     level_done = None
