@@ -8,6 +8,7 @@ in the scatter epilogue) so bit equality is not expected; and the reference's
 own acceptance bar, scaled backward error <= 1e-14 (src/utils_mod.F90:462-467).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -846,6 +847,43 @@ def test_bench_workload_full_size_properties():
     assert np.abs(L2 - L1).max() <= 1e-13 * np.abs(L1).max()
     L4 = f.factor(4.0 * val).wait().get_factor()
     assert np.abs(L4 - 2.0 * L1).max() <= 1e-13 * np.abs(L1).max()
+
+
+_FULL = ["poisson3d_128", "serena_like"] + (["flan_like"] if os.environ.get("SPLLT_TEST_FLAN") else [])
+
+
+@pytest.mark.parametrize("name", _FULL)
+def test_large_configs_full_size_against_the_oracle(name):
+    """BASELINE configs 3 and 5 (and 4 = flan_like with SPLLT_TEST_FLAN=1: 33 GB of factor, ~1.5 min of CPU
+    oracle) at their FULL size on one GPU: every entry of L against the CPU oracle (MKL + OpenMP tasks,
+    all host cores), max|dL| / max|L| <= 1e-12, and the reference's residual bar.  12-18 TFLOP each;
+    the oracle takes 15-25 s, the GPU 0.25-0.32 s."""
+    A, order, cfg = matgen.build_config(name, 1.0)
+    n, ptr, row, val = api.csc_lower_1based(A)
+    f = api.Factorization(n, ptr, row, nb=cfg["nb"], nemin=32, prune_tree=False, order=order)
+    got = f.factor(val).wait().get_factor()
+    o, rc = oracle_factor(f, val, variant="mkl", nthreads=min(16, len(os.sched_getaffinity(0))))
+    assert rc == 0
+    ref = o.arena()
+    # the strict upper triangle of the diagonal tiles is never read by anybody (SURVEY Appendix A):
+    # cleared on both sides, then the arenas are compared whole, in pieces
+    off, bw = f.sym("bcol_off"), f.sym("bcol_width")
+    tri = {}
+    for b in range(len(off)):
+        w = int(bw[b])
+        if w not in tri:
+            tri[w] = np.triu_indices(w, 1)
+        for arr in (got, ref):
+            arr[int(off[b]):int(off[b]) + w * w].reshape(w, w)[tri[w]] = 0.0
+    err, top = 0.0, 0.0
+    step = 1 << 27
+    for a in range(0, got.size, step):
+        err = max(err, float(np.abs(got[a:a + step] - ref[a:a + step]).max()))
+        top = max(top, float(np.abs(ref[a:a + step]).max()))
+    assert err <= TOL_L * top, (err, top)
+    b = A @ np.ones(n)
+    assert bwd_err(A, f.solve(b), b) <= 1e-14
+    f.close()
 
 
 def test_solve_dev_on_device_vectors():
