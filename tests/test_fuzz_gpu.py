@@ -1,6 +1,8 @@
 """Seeded fuzz of the HIP factor + solve path over matrix shapes and tile / panel /
 amalgamation options that divide nothing evenly (nb 5..200, panel width 4..64,
 nemin 1..64, engine variants), each against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -22,7 +24,7 @@ def _random_spd(rng, n, density):
     return (S + sp.diags(d)).tocsc()
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPLLT_FUZZ_SEEDS", "64"))))    # (a longer campaign: SPLLT_FUZZ_SEEDS=1024)
 def test_fuzz_factor_and_solve(seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     # every third case with chain blocks of four panels (k_chain_block + k_trsm_rows: ragged panel
