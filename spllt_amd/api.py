@@ -46,7 +46,7 @@ GATHER_TILE_DTYPE = np.dtype([("d_off", "<i8"), ("d_ld", "<i4"), ("row0", "<i4")
 LAUNCH_COLS = ("kind", "level", "first", "count", "tile", "flops", "stream", "record",
                "wait0", "wait1", "wait2", "wait3")
 SOLVE_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("idx_off", "<i8"), ("w", "<i4"),
-                             ("nrow", "<i4"), ("pw", "<i4"), ("cb", "<i4")])
+                             ("nrow", "<i4"), ("pw", "<i4"), ("cb", "<i4"), ("gcol0", "<i4"), ("pad_", "<i4")])
 POTRF_UNIT_DTYPE = np.dtype([("off", "<i8"), ("dinv_off", "<i8"), ("ld", "<i4"), ("n", "<i4"),
                              ("gcol", "<i4"), ("flags", "<i4")])
 

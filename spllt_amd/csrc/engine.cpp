@@ -1436,8 +1436,20 @@ int Engine::solve_dev(double* y_dev, int nrhs, int job, int phase) {
         bool four = solve_four_ && (ls[i].kind == SV_DIAG_FWD || ls[i].kind == SV_DIAG_BWD);
         for (int64_t q = ls[i].first; four && q < ls[i].first + ls[i].count; ++q)
           four = sprog_.units[(size_t)sprog_.diag_list[(size_t)q]].w <= 256;
+        // a launch on ONE block column (every step of the upper levels): its descriptor by value
+        const SolveUnit* one = nullptr;
+        if (ls[i].count > 0) {
+          if (ls[i].kind == SV_DIAG_FWD || ls[i].kind == SV_DIAG_BWD) {
+            if (ls[i].count == 1) one = &sprog_.units[(size_t)sprog_.diag_list[(size_t)ls[i].first]];
+          } else {
+            const UpdTile* tl = sprog_.tiles.data() + ls[i].first;
+            bool same = true;
+            for (int64_t q = 0; same && q < ls[i].count; ++q) same = tl[q].unit == tl[0].unit && tl[q].ti == (short)q;
+            if (same && ls[i].count < 32768) one = &sprog_.units[(size_t)tl[0].unit];
+          }
+        }
         launch_solve(stream_, ls[i].kind, d_slist_, d_stiles_, ls[i].first, ls[i].count, d_sunits_, d_L_,
-                     d_dinv_, d_rlist_, y, cur, (int64_t)n, four);
+                     d_dinv_, d_rlist_, y, cur, (int64_t)n, four, one);
       }
     };
     const size_t nf = sprog_.fwd.size(), nb = sprog_.bwd.size();

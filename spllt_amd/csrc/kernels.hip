@@ -2244,18 +2244,19 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
                                                     const double* __restrict__ L,
                                                     const double* __restrict__ dinv,
                                                     const int* __restrict__ rlist,
-                                                    double* __restrict__ y, int64_t ldy) {
+                                                    double* __restrict__ y, int64_t ldy, const SolveUnit u0, int single) {
   __shared__ double xb[NR * kXS];
   __shared__ double tb[NR * 64];
   __shared__ double part[4][NR * 64];
-  const SolveUnit u = units[list[blockIdx.x]];
+  // (single: the launch has ONE block column -- every step of the upper levels -- and its descriptor
+  // came with the kernel arguments instead of through two dependent loads)
+  const SolveUnit u = single ? u0 : units[list[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = tid & 15, rr = tid >> 4;   // 16 lanes per row, 16 rows per pass
   const int w = u.w, pw = u.pw;
   const double* A = L + u.off;
-  const int* idx = rlist + u.idx_off;
   for (int j = tid; j < w; j += 256) {
-    const int gi = idx[j];
+    const int gi = u.gcol0 + j;          // (the block column's own columns are consecutive pivot positions)
 #pragma unroll
     for (int q = 0; q < NR; ++q) xb[q * kXS + j] = y[q * ldy + gi];
   }
@@ -2388,7 +2389,7 @@ __global__ __launch_bounds__(256) void k_solve_diag(const int* __restrict__ list
     }
   }
   for (int j = tid; j < w; j += 256) {
-    const int gi = idx[j];
+    const int gi = u.gcol0 + j;          // (the block column's own columns are consecutive pivot positions)
 #pragma unroll
     for (int q = 0; q < NR; ++q) y[q * ldy + gi] = xb[q * kXS + j];
   }
@@ -2407,17 +2408,16 @@ __global__ __launch_bounds__(256) void k_solve_diag4(const int* __restrict__ lis
                                                      const double* __restrict__ L,
                                                      const double* __restrict__ dinv,
                                                      const int* __restrict__ rlist,
-                                                     double* __restrict__ y, int64_t ldy) {
+                                                     double* __restrict__ y, int64_t ldy, const SolveUnit u0, int single) {
   __shared__ double xb[NR * 256];
   __shared__ double tb[NR * 64];
   __shared__ double part[4][NR * 64];
-  const SolveUnit u = units[list[blockIdx.x]];
+  const SolveUnit u = single ? u0 : units[list[blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = tid & 15, rr = tid >> 4;   // forward: 16 lanes per row, 16 rows per pass
   const int w = u.w;
   const int np = (w + 63) >> 6;
   const double* A = L + u.off;
-  const int* idx = rlist + u.idx_off;
   // ---- everything of L the steps will read ------------------------------------------------
   double lv[3][4][12];       // forward: panel p + 1, row rr + 16 r, columns sub + 16 e (e < 4 (p + 1))
   double bv[3][48];          // backward: panel p, column lane, rows 64 (p + 1) + wave + 4 i (i < 16 (3 - p))
@@ -2462,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_solve_diag4(const int* __restrict__ lis
   double dv[16], dvn[16];
   wload(BWD ? np - 1 : 0, dv);
   for (int j = tid; j < w; j += 256) {
-    const int gi = idx[j];
+    const int gi = u.gcol0 + j;          // (the block column's own columns are consecutive pivot positions)
 #pragma unroll
     for (int q = 0; q < NR; ++q) xb[q * 256 + j] = y[q * ldy + gi];
   }
@@ -2576,7 +2576,7 @@ __global__ __launch_bounds__(256) void k_solve_diag4(const int* __restrict__ lis
     for (int e = 0; e < 16; ++e) dv[e] = dvn[e];
   }
   for (int j = tid; j < w; j += 256) {
-    const int gi = idx[j];
+    const int gi = u.gcol0 + j;          // (the block column's own columns are consecutive pivot positions)
 #pragma unroll
     for (int q = 0; q < NR; ++q) y[q * ldy + gi] = xb[q * 256 + j];
   }
@@ -2590,19 +2590,20 @@ __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__
                                                      const SolveUnit* __restrict__ units,
                                                      const double* __restrict__ L,
                                                      const int* __restrict__ rlist,
-                                                     double* __restrict__ y, int64_t ldy) {
+                                                     double* __restrict__ y, int64_t ldy, const SolveUnit u0, int single) {
   __shared__ double xb[NR * kXS];
-  const UpdTile tl = tiles[blockIdx.x];
-  const SolveUnit u = units[tl.unit];
+  // (single: all strips of the launch belong to ONE block column, strip i = workgroup i)
+  const int ti = single ? (int)blockIdx.x : (int)tiles[blockIdx.x].ti;
+  const SolveUnit u = single ? u0 : units[tiles[blockIdx.x].unit];
   const int tid = threadIdx.x;
   const int w = u.w;
-  const int r0 = w + (int)tl.ti * kSolveStripRows;
+  const int r0 = w + ti * kSolveStripRows;
   const int nr = min(kSolveStripRows, u.nrow - r0);
   const double* A = L + u.off + (int64_t)r0 * w;
   const int* idx = rlist + u.idx_off;
   if (!BWD) {
     for (int k = tid; k < w; k += 256) {
-      const int gi = idx[k];
+      const int gi = u.gcol0 + k;
 #pragma unroll
       for (int q = 0; q < NR; ++q) xb[q * kXS + k] = y[q * ldy + gi];
     }
@@ -2645,7 +2646,7 @@ __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__
           for (int q = 0; q < NR; ++q) sa[q] = __builtin_fma(a, xb[q * kXS + min(q0 + e, nr - 1)], sa[q]);
         }
       }
-      const int gi = idx[k];
+      const int gi = u.gcol0 + k;
 #pragma unroll
       for (int q = 0; q < NR; ++q) unsafeAtomicAdd(y + q * ldy + gi, -sa[q]);
     }
@@ -2655,26 +2656,29 @@ __global__ __launch_bounds__(256) void k_solve_strip(const UpdTile* __restrict__
 template <int NR>
 static void launch_solve_nr(hipStream_t st, int kind, const int* list, const UpdTile* tiles,
                             int64_t first, int64_t count, const SolveUnit* units, const double* L,
-                            const double* dinv, const int* rlist, double* y, int64_t ldy, bool four) {
+                            const double* dinv, const int* rlist, double* y, int64_t ldy, bool four,
+                            const SolveUnit* one) {
   const dim3 g((unsigned)count), b(256);
+  const SolveUnit u0 = one ? *one : SolveUnit{};
+  const int single = one ? 1 : 0;
   switch (kind) {
     case SV_DIAG_FWD:
       if (four)
-        hipLaunchKernelGGL((k_solve_diag4<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+        hipLaunchKernelGGL((k_solve_diag4<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy, u0, single);
       else
-        hipLaunchKernelGGL((k_solve_diag<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+        hipLaunchKernelGGL((k_solve_diag<false, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy, u0, single);
       break;
     case SV_DIAG_BWD:
       if (four)
-        hipLaunchKernelGGL((k_solve_diag4<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+        hipLaunchKernelGGL((k_solve_diag4<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy, u0, single);
       else
-        hipLaunchKernelGGL((k_solve_diag<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy);
+        hipLaunchKernelGGL((k_solve_diag<true, NR>), g, b, 0, st, list + first, units, L, dinv, rlist, y, ldy, u0, single);
       break;
     case SV_STRIP_FWD:
-      hipLaunchKernelGGL((k_solve_strip<false, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy);
+      hipLaunchKernelGGL((k_solve_strip<false, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy, u0, single);
       break;
     default:
-      hipLaunchKernelGGL((k_solve_strip<true, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy);
+      hipLaunchKernelGGL((k_solve_strip<true, NR>), g, b, 0, st, tiles + first, units, L, rlist, y, ldy, u0, single);
       break;
   }
 }
@@ -2682,14 +2686,14 @@ static void launch_solve_nr(hipStream_t st, int kind, const int* list, const Upd
 // nr = 1, 2 or 4 right-hand sides per sweep: y[q * ldy + i]
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y, int nr, int64_t ldy, bool four) {
+                  const int* rlist, double* y, int nr, int64_t ldy, bool four, const SolveUnit* one) {
   if (count <= 0) return;
   if (nr >= 4)
-    launch_solve_nr<4>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
+    launch_solve_nr<4>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four, one);
   else if (nr >= 2)
-    launch_solve_nr<2>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
+    launch_solve_nr<2>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four, one);
   else
-    launch_solve_nr<1>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four);
+    launch_solve_nr<1>(st, kind, list, tiles, first, count, units, L, dinv, rlist, y, ldy, four, one);
 }
 
 // ---------------------------------------------------------------------------

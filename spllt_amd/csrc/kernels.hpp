@@ -79,7 +79,9 @@ void launch_scatter_block(hipStream_t st, int s_m, int s_n, const int* rsrc_inde
 // most four 64-wide panels (pw = cb = 64, w <= 256) -- the kernel that reads L in one round trip
 void launch_solve(hipStream_t st, int kind, const int* list, const UpdTile* tiles, int64_t first,
                   int64_t count, const SolveUnit* units, const double* L, const double* dinv,
-                  const int* rlist, double* y, int nr, int64_t ldy, bool four = false);
+                  const int* rlist, double* y, int nr, int64_t ldy, bool four = false,
+                  const SolveUnit* one = nullptr);   // one: the launch works on ONE block column (host copy of its unit;
+                                                     // strips: strip i = workgroup i) -- the descriptor travels with the arguments
 void launch_expand_buffer(hipStream_t st, double* a, int blkn, const int* row_list, int rls,
                           const int* col_list, int cls, int ndiag, const double* buffer);
 

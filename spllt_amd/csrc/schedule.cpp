@@ -1426,6 +1426,8 @@ void build_solve_program(const Symbolic& S, int pw, int cb, SolveProgram& P, con
       u.nrow = B.nrow;
       u.pw = pw;
       u.cb = cb;
+      u.gcol0 = S.sptr[B.node] + B.r0;
+      u.pad_ = 0;
       o += winv_total(B.width, cb);
     }
   }

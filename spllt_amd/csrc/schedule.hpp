@@ -380,7 +380,10 @@ struct SolveUnit {
   int nrow;          // rows stored (w diagonal rows + rows below)
   int pw;            // panel width
   int cb;            // chain block (Winv layout, see ChainUnit)
+  int gcol0;         // pivot position of column 0: rlist[idx_off + j] = gcol0 + j for j < w (the block column's
+  int pad_;          // own columns are consecutive: the kernels skip that index load)
 };
+static_assert(sizeof(SolveUnit) == 48, "SolveUnit layout (mirrored in spllt_amd/api.py)");
 
 enum SolveKind : int { SV_DIAG_FWD = 0, SV_STRIP_FWD = 1, SV_STRIP_BWD = 2, SV_DIAG_BWD = 3 };
 
