@@ -129,7 +129,7 @@ def _partitioned_factor_and_solve(A, world, nb, nemin, pw, flags=0):
     return fs, val, got, B
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPLLT_FUZZ_PART_SEEDS", "16"))))
 def test_fuzz_partitioned_factor_and_solve(seed, monkeypatch):
     """subtree partition over 2..5 ranks (some may own nothing, the top tree may be
     one node) on random shapes: L of every rank against the oracle on the block
