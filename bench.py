@@ -189,7 +189,9 @@ def run_small_config(label, A, nb, nemin, steps=30):
     out = {"workload": label, "n": n, "nb": nb}
     for mode, flag in (("default", 0), ("eager", 131072), ("graph_chain", 32768), ("graph_dag", 65536)):
         f = api.Factorization(n, ptr, row, nb=nb, nemin=nemin, prune_tree=False, engine_flags=flag)
-        for _ in range(3):
+        # (the chip needs ~100 ms of load to reach its clocks, profiles/r03/sustain_probe.txt: the first
+        # mode measured is not to pay for that)
+        for _ in range(300 if mode == "default" else 20):
             f.factor_dev(dval.data_ptr()).wait()
         torch.cuda.synchronize()
         sub, dev = [], []

@@ -152,11 +152,14 @@ int64_t spllt_hip_sym_get(const void *akeep, const char *name, void *buf, int64_
  * (default: by the weight of the top tree, see spllt_hip_set_partition).
  * Bit 15 / bit 16 = HIP-graph replay of the factorization (analyse once, factorize many): one
  * graph per pattern built from the program tables, a chain of kernel nodes in program order / the
- * DAG of the multi-stream program; bit 17 = eager launches.  Default: by problem size -- the
- * chain replay up to 5 GFLOP (0.35 vs 0.48 ms at the smoke size, 0.46 vs 0.69 ms on BASELINE
- * config 1: there the host's submission is as long as the device's work), the DAG replay up to
- * 40 GFLOP, eager above (on ROCm 7.2 hipGraphLaunch submits nothing before all nodes are
- * enqueued: 25.1 / 24.4 ms against 23.7 eager on the 650 launches of the bench workload).
+ * DAG of the multi-stream program; bit 17 = eager launches.  Default: by problem size -- up to
+ * 40 GFLOP the chain replay, and for it the SINGLE-STREAM program (a chain runs in program order
+ * anyway: no zones, slices, markers or events -- 27 instead of 36 kernels on BASELINE config 1):
+ * 0.22 vs 0.48 ms eager at the smoke size, 0.36 vs 0.69 ms on BASELINE config 1, 2.80 vs 3.28 ms at
+ * 19 GFLOP, 4.02 vs 4.66 ms at 33 GFLOP; eager launches above (level at 313 GFLOP: on ROCm 7.2
+ * hipGraphLaunch submits nothing before all nodes are enqueued; 25.1 / 24.4 ms against 23.7 eager
+ * on the 650 launches of the bench workload).  SPLLT_CHAIN_GRAPH_SERIAL=0 keeps the multi-stream
+ * program under the chain replay.
  * Bit 18 / bit 19 = small subtrees as single device tasks on / off (L_SUBTREE, k_subtree: one
  * workgroup factorizes a whole subtree of one-panel nodes in post-order, what leaves the subtree
  * goes through a private generated element and reaches the ancestors in ONE extend-add from the

@@ -320,12 +320,36 @@ hipError_t Engine::dev_upload(Tp** dptr, const std::vector<Tp>& v) {
 // EngineOptions -> ScheduleOptions, in ONE place (the engine and the host-only program of
 // spllt_hip_program_get / the CPU tests must build the same program); resolves the "-1 = decide by
 // the problem" options of opt in place.
+int resolve_graph_mode(const Symbolic& S, const EngineOptions& opt) {
+  int mode = opt.graph;
+  if (const char* e = std::getenv("SPLLT_HIP_GRAPH")) mode = std::atoi(e);
+  if (mode < 0) {
+    // by problem size (profiles/r04/graph_replay_by_size.txt): a small factorization is a few dozen
+    // launches whose submission takes the host as long as the device needs for them -- the replay of
+    // ONE chain of kernel nodes over the single-stream program wins 45-50 % at the small end (0.22 vs
+    // 0.48 ms at the smoke size, 0.36 vs 0.69 ms on BASELINE config 1), 15 % at 19-33 GFLOP (2.80 /
+    // 4.02 ms against 3.28 / 4.66 eager and 3.04 / 4.38 as the DAG replay), and is level with eager
+    // launches at 313 GFLOP (hipGraphLaunch submits nothing before all nodes are enqueued)
+    const double fl = (double)S.flops;
+    mode = fl <= 40e9 ? 1 : 0;
+  }
+  if (opt.nranks > 1 || opt.poison_lds) mode = 0;      // (single-GPU programs without the debug poison only)
+  return mode;
+}
+
 ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt) {
   ScheduleOptions so;
   so.pw = opt.pw;
   so.tile = opt.tile;
   so.cb = opt.cb;
   so.lookahead = opt.lookahead;
+  // a factorization that is replayed as ONE chain of kernel nodes runs in program order anyway: it gets
+  // the single-stream program -- no zones, no early slices, no markers: 27 instead of 36 kernels on
+  // BASELINE config 1 (profiles/r04/graph_replay_by_size.txt)
+  {
+    const char* e = std::getenv("SPLLT_CHAIN_GRAPH_SERIAL");      // (0: the multi-stream program, replayed in program order)
+    if (!(e && std::atoi(e) == 0) && resolve_graph_mode(S, opt) == 1) so.lookahead = false;
+  }
   so.slice_between = opt.slice_between;
   so.deterministic = opt.deterministic;
   so.fused_panel = opt.fused_panel;
@@ -569,17 +593,7 @@ int Engine::upload() {
   // launch-to-completion beside a masked bulk kernel, 30 us beside an unmasked one; masking
   // the FIRST bits instead gives erratic 13-450 us).  The wide stream (launches that have
   // the chip to themselves) is not masked.
-  graph_mode_ = opt_.graph;
-  if (const char* e = std::getenv("SPLLT_HIP_GRAPH")) graph_mode_ = std::atoi(e);
-  if (graph_mode_ < 0) {
-    // by problem size (profiles/r04/graph_replay_by_size.txt): a small factorization is a few dozen
-    // launches whose submission takes the host as long as the device needs for them -- the replay of
-    // ONE graph wins 20-40 % up to ~3 GFLOP (0.35 vs 0.48 ms at the smoke size, 0.46 vs 0.69 ms on
-    // BASELINE config 1), a few per cent up to ~30 GFLOP, and loses from a few hundred launches on
-    // (hipGraphLaunch submits nothing before all nodes are enqueued: 13.6 vs 12.0 ms at 313 GFLOP)
-    const double fl = (double)S.flops;
-    graph_mode_ = fl <= 5e9 ? 1 : (fl <= 40e9 ? 2 : 0);
-  }
+  graph_mode_ = resolve_graph_mode(S, opt_);
   if (const char* e = std::getenv("SPLLT_CHAIN_PRIO")) chain_prio_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD128")) bulk_pad128_ = std::atoi(e);
   if (const char* e = std::getenv("SPLLT_BULK_PAD64")) bulk_pad64_ = std::atoi(e);

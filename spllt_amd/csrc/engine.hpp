@@ -59,6 +59,9 @@ struct FactorStats {
 
 // EngineOptions -> ScheduleOptions (the one place); resolves the "decide by the problem" options of opt
 ScheduleOptions schedule_options(const Symbolic& S, EngineOptions& opt);
+// HIP-graph replay of a factorization of S: 0 eager launches, 1 one chain of kernel nodes, 2 the DAG of the
+// multi-stream program (opt.graph, env SPLLT_HIP_GRAPH, or by problem size)
+int resolve_graph_mode(const Symbolic& S, const EngineOptions& opt);
 
 // Partition of the tree for opt.nranks ranks: node owners, and (distributed top tree) the owners of
 // the top-tree block columns; fills the partition fields of so (the vectors must outlive it).

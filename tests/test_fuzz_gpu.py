@@ -35,6 +35,9 @@ def test_fuzz_factor_and_solve(seed, monkeypatch):
     # tasks of one node, of a few, and of whole trees
     monkeypatch.setenv("SPLLT_SUBTREES", str(seed // 2 % 2))
     monkeypatch.setenv("SPLLT_SUBTREE_US", str([40, 300, 5000][seed % 3]))
+    # (the chain replay of a small factorization: the single-stream program, the library's default, or the
+    # multi-stream program in program order)
+    monkeypatch.setenv("SPLLT_CHAIN_GRAPH_SERIAL", str(seed // 4 % 2))
     kind = seed % 4
     if kind == 0:
         A = matgen.nd_like(tuple(int(x) for x in rng.integers(4, 11, size=3)), int(rng.integers(1, 3)))

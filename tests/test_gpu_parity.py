@@ -699,6 +699,34 @@ def test_subtree_tasks_match_oracle(gen, nb, pw, nemin, budget, graph, monkeypat
     f.close()
 
 
+@pytest.mark.parametrize("gen,nb,nemin", [(lambda: matgen.poisson2d(128), 256, 32),          # BASELINE config 1
+                                          (lambda: matgen.poisson2d(48), 32, 16),
+                                          (lambda: matgen.nd_like((12, 11, 10), 2), 64, 16)])
+def test_default_replay_of_small_factorizations(gen, nb, nemin, monkeypatch):
+    """The library's default for a small factorization: ONE chain of kernel nodes over the SINGLE-STREAM
+    program (the test-suite otherwise keeps the multi-stream program, conftest.py).  Against the oracle,
+    over new values on the same pattern, and a not-positive-definite input reported through the graph."""
+    monkeypatch.setenv("SPLLT_CHAIN_GRAPH_SERIAL", "1")
+    monkeypatch.delenv("SPLLT_HIP_GRAPH", raising=False)
+    A = gen()
+    f, val = make_case(A, nb=nb, nemin=nemin)
+    L = f.program("launches")
+    assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all()
+    for scale in (1.0, 0.25, 3.0):
+        got = f.factor(val * scale).wait().get_factor()
+        o, rc = oracle_factor(f, val * scale)
+        assert rc == 0
+        assert rel_err(got, o.arena(), lower_mask(f)) <= TOL_L
+    b = (A * 3.0) @ np.ones(f.n)
+    assert bwd_err(A * 3.0, f.solve(b), b) <= 1e-14
+    bad = val.copy()
+    bad[0] = -1.0
+    with pytest.raises(api.SplltError) as ei:
+        f.factor(bad).wait()
+    assert ei.value.flag == -20
+    f.close()
+
+
 @pytest.mark.parametrize("flags", [32768, 65536, 65536 | 4096, 32768 | 512, 65536 | 2048])
 def test_graph_replay_matches_oracle(flags):
     """SURVEY 8(f) row f1, analyse once / factorize many (reference kernels_mod:2301-2364): the

@@ -505,3 +505,25 @@ def test_subtree_tasks_are_opt_in(monkeypatch):
     for fl in (4096, 262144 | 4096):                                                  # never in the deterministic engine
         f3, _ = make_case(matgen.poisson2d(40), nb=64, nemin=8, engine_flags=fl)
         assert not (f3.program("launches")[:, 0] == 10).any()
+
+
+def test_chain_replay_gets_the_single_stream_program(monkeypatch):
+    """A factorization small enough to be replayed as ONE chain of graph nodes (the default up to 40 GFLOP)
+    is built as the single-stream program -- no zones, slices, markers or events: fewer kernels in the
+    chain -- unless the caller asks for eager launches / the DAG replay, or the problem is large."""
+    monkeypatch.setenv("SPLLT_CHAIN_GRAPH_SERIAL", "1")
+    A = matgen.poisson2d(40)
+    f, val = make_case(A, nb=64, nemin=8)
+    L = f.program("launches")
+    assert (L[:, 6] == 0).all() and (L[:, 7:] == -1).all() and (L[:, 3] > 0).all()
+    f2, _ = make_case(A, nb=64, nemin=8, engine_flags=2)                  # the explicit single-stream program
+    assert np.array_equal(L, f2.program("launches"))
+    for fl in (65536, 131072):                                               # DAG replay / eager: multi-stream
+        f3, _ = make_case(A, nb=64, nemin=8, engine_flags=fl)
+        L3 = f3.program("launches")
+        assert (L3[:, 6] != 0).any() and (L3[:, 7] >= 0).any() and len(L3) > len(L)
+    monkeypatch.setenv("SPLLT_CHAIN_GRAPH_SERIAL", "0")
+    f4, _ = make_case(A, nb=64, nemin=8)
+    assert len(f4.program("launches")) > len(L)
+    got = emulate_program(f, val)
+    assert rel_err(got, dense_arena(f, A), lower_mask(f)) < 1e-13
